@@ -1,0 +1,33 @@
+#!/usr/bin/env bash
+# Builds, in-tree:
+#   bulletproofs_gadgets_amd/libbpg.so     the product (HIP kernels + C ABI), gfx950 only
+#   oracle/liboracle.so                    the CPU checker (test infrastructure)
+#   tests/native/libhost_hooks.so          host instantiation of the arithmetic headers (test only)
+# hipcc cross-compiles for gfx950 without a GPU present.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+ARCH=gfx950
+SRC=bulletproofs_gadgets_amd/csrc
+OUT=bulletproofs_gadgets_amd
+mkdir -p build
+HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function -Iinclude"
+
+objs=()
+for f in ${SRC}/*.hip; do
+    o=build/$(basename "${f%.hip}").o
+    if [[ ! -f $o || $f -nt $o || -n $(find ${SRC} include -name '*.h' -newer "$o" -print -quit) ]]; then
+        echo "hipcc $f"
+        $HIPCC $HIPFLAGS -c "$f" -o "$o" &
+    fi
+    objs+=("$o")
+done
+wait
+$HIPCC -shared -fPIC --offload-arch=${ARCH} -o ${OUT}/libbpg.so "${objs[@]}" -Wl,-rpath,/opt/rocm/lib -lpthread
+echo "built ${OUT}/libbpg.so"
+
+make -s -C oracle
+echo "built oracle/liboracle.so"
+
+$HIPCC -O2 -std=c++17 -fPIC --offload-arch=${ARCH} -shared -o tests/native/libhost_hooks.so tests/native/host_hooks.hip -Wl,-rpath,/opt/rocm/lib
+echo "built tests/native/libhost_hooks.so"

@@ -1,0 +1,218 @@
+"""ctypes binding of libbpg.so (include/bpg.h).
+
+The HIP library is the product; there is no Python or CPU fallback.  Importing
+this module never touches the GPU; `Context()` does, and raises if the
+extension or the device is missing.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbpg.so")
+
+OK = 0
+EINVAL, EDEVICE, EFORMAT, EVERIFY, EGENS, EMISSING, EGADGET, ENOMEM = -1, -2, -3, -4, -5, -6, -7, -8
+_ERR_NAMES = {
+    EINVAL: "BPG_EINVAL", EDEVICE: "BPG_EDEVICE", EFORMAT: "BPG_EFORMAT", EVERIFY: "BPG_EVERIFY",
+    EGENS: "BPG_EGENS", EMISSING: "BPG_EMISSING", EGADGET: "BPG_EGADGET", ENOMEM: "BPG_ENOMEM",
+}
+
+
+class BpgError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (_ERR_NAMES.get(code, "BPG_E?"), code, ": " + detail if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Load libbpg.so (built in-tree by build.sh / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            "bulletproofs_gadgets_amd: %s is missing. Build it with ./build.sh (hipcc, gfx950). "
+            "There is no CPU fallback." % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, sz, cp, ip = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)
+    pvp = ctypes.POINTER(ctypes.c_void_p)
+    fp = ctypes.POINTER(ctypes.c_float)
+    psz = ctypes.POINTER(ctypes.c_size_t)
+    sigs = {
+        "bpg_init": (ctypes.c_int, [ctypes.c_int, pvp]),
+        "bpg_shutdown": (None, [vp]),
+        "bpg_last_error": (cp, []),
+        "bpg_version": (cp, []),
+        "bpg_device_alloc": (ctypes.c_int, [vp, sz, pvp]),
+        "bpg_device_free": (ctypes.c_int, [vp, vp]),
+        "bpg_copy_to_device": (ctypes.c_int, [vp, vp, cp, sz]),
+        "bpg_copy_to_host": (ctypes.c_int, [vp, vp, vp, sz]),
+        "bpg_synchronize": (ctypes.c_int, [vp]),
+        "bpg_points_from_compressed": (ctypes.c_int, [vp, cp, sz, pvp]),
+        "bpg_points_from_uniform": (ctypes.c_int, [vp, cp, sz, pvp]),
+        "bpg_points_compress": (ctypes.c_int, [vp, vp, sz, sz, vp]),
+        "bpg_points_len": (sz, [vp]),
+        "bpg_points_free": (None, [vp]),
+        "bpg_msm": (ctypes.c_int, [vp, vp, cp, sz, vp]),
+        "bpg_msm_submit": (ctypes.c_int, [vp, vp, vp, sz, sz, pvp]),
+        "bpg_msm_submit_segments": (ctypes.c_int, [vp, vp, psz, psz, sz, vp, sz, pvp]),
+        "bpg_msm_wait": (ctypes.c_int, [vp, vp]),
+        "bpg_msm_plan": (ctypes.c_int, [vp, sz, sz, ip, ip, ip, ip]),
+        "bpg_msm_last_kernel_us": (ctypes.c_int, [vp, fp, fp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)        # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    L._bpg_sigs = sigs
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names declared in include/bpg.h that this binding expects the library to export."""
+    return sorted(lib()._bpg_sigs.keys())
+
+
+def check(rc):
+    if rc != OK:
+        raise BpgError(rc, (lib().bpg_last_error() or b"").decode(errors="replace"))
+
+
+class Points:
+    """Resident table of points in HBM (affine Niels form)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+
+    def __len__(self):
+        return lib().bpg_points_len(self._h)
+
+    def compress(self, start=0, n=None):
+        n = len(self) - start if n is None else n
+        out = ctypes.create_string_buffer(32 * n if n else 1)
+        check(lib().bpg_points_compress(self.ctx._h, self._h, start, n, out))
+        return out.raw[: 32 * n]
+
+    def free(self):
+        if self._h:
+            lib().bpg_points_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = ctypes.c_void_p()
+        check(lib().bpg_device_alloc(ctx._h, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, data):
+        assert len(data) <= self.nbytes
+        check(lib().bpg_copy_to_device(self.ctx._h, self.ptr, data, len(data)))
+        return self
+
+    def download(self, nbytes=None):
+        nbytes = self.nbytes if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(nbytes if nbytes else 1)
+        check(lib().bpg_copy_to_host(self.ctx._h, out, self.ptr, nbytes))
+        return out.raw[:nbytes]
+
+    def free(self):
+        if self.ptr:
+            lib().bpg_device_free(self.ctx._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MsmJob:
+    def __init__(self, ctx, handle, n_targets):
+        self.ctx, self._h, self.n_targets = ctx, handle, n_targets
+
+    def wait(self):
+        out = ctypes.create_string_buffer(32 * self.n_targets)
+        check(lib().bpg_msm_wait(self._h, out))
+        return out.raw
+
+
+class Context:
+    """One per process / GPU."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        check(lib().bpg_init(device, ctypes.byref(h)))
+        self._h = h.value
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().bpg_shutdown(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        check(lib().bpg_synchronize(self._h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def points_from_compressed(self, data):
+        assert len(data) % 32 == 0
+        h = ctypes.c_void_p()
+        check(lib().bpg_points_from_compressed(self._h, data, len(data) // 32, ctypes.byref(h)))
+        return Points(self, h.value)
+
+    def points_from_uniform(self, data):
+        assert len(data) % 64 == 0
+        h = ctypes.c_void_p()
+        check(lib().bpg_points_from_uniform(self._h, data, len(data) // 64, ctypes.byref(h)))
+        return Points(self, h.value)
+
+    def msm(self, points, scalars):
+        """compress(sum_i scalars[i] * points[i]); scalars = n x 32 bytes."""
+        assert len(scalars) % 32 == 0
+        out = ctypes.create_string_buffer(32)
+        check(lib().bpg_msm(self._h, points._h, scalars, len(scalars) // 32, out))
+        return out.raw
+
+    def msm_submit(self, points, d_scalars_ptr, n, n_targets=1, segments=None):
+        h = ctypes.c_void_p()
+        if segments is None:
+            check(lib().bpg_msm_submit(self._h, points._h, d_scalars_ptr, n, n_targets, ctypes.byref(h)))
+        else:
+            k = len(segments)
+            starts = (ctypes.c_size_t * k)(*[s for s, _ in segments])
+            lens = (ctypes.c_size_t * k)(*[l for _, l in segments])
+            assert sum(l for _, l in segments) == n
+            check(lib().bpg_msm_submit_segments(self._h, points._h, starts, lens, k, d_scalars_ptr, n_targets,
+                                                ctypes.byref(h)))
+        return MsmJob(self, h.value, n_targets)
+
+    def msm_plan(self, n, n_targets=1):
+        c, w, nb, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().bpg_msm_plan(self._h, n, n_targets, ctypes.byref(c), ctypes.byref(w), ctypes.byref(nb), ctypes.byref(p)))
+        return {"window_bits": c.value, "windows": w.value, "buckets": nb.value, "threads_per_bucket": p.value}
+
+    def msm_last_kernel_us(self):
+        a, t = ctypes.c_float(), ctypes.c_float()
+        check(lib().bpg_msm_last_kernel_us(self._h, ctypes.byref(a), ctypes.byref(t)))
+        return a.value, t.value

@@ -1,0 +1,294 @@
+// api.hip -- C-ABI entry points (include/bpg.h): context, device memory helpers,
+// resident point tables (batch ristretto decode / Elligator / compress kernels),
+// and the MSM entry points.  No CPU fallback: bpg_init fails without a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "bpg_internal.h"
+
+namespace bpg {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char *what, hipError_t e) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+}
+void set_last_error_msg(const char *what) { snprintf(g_err, sizeof g_err, "%s", what); }
+
+__device__ __forceinline__ void store_aniels(aniels_rec *rec, const ge_aniels &q) {
+    uint4 *p = reinterpret_cast<uint4 *>(rec);
+    p[0] = make_uint4(q.YpX.v[0], q.YpX.v[1], q.YpX.v[2], q.YpX.v[3]);
+    p[1] = make_uint4(q.YpX.v[4], q.YpX.v[5], q.YpX.v[6], q.YpX.v[7]);
+    p[2] = make_uint4(q.YmX.v[0], q.YmX.v[1], q.YmX.v[2], q.YmX.v[3]);
+    p[3] = make_uint4(q.YmX.v[4], q.YmX.v[5], q.YmX.v[6], q.YmX.v[7]);
+    p[4] = make_uint4(q.T2d.v[0], q.T2d.v[1], q.T2d.v[2], q.T2d.v[3]);
+    p[5] = make_uint4(q.T2d.v[4], q.T2d.v[5], q.T2d.v[6], q.T2d.v[7]);
+    p[6] = make_uint4(0, 0, 0, 0);
+    p[7] = make_uint4(0, 0, 0, 0);
+}
+
+// CompressedRistretto::decompress per thread; invalid encodings raise *bad and store the identity
+__global__ void __launch_bounds__(256) k_decode(const uint8_t *__restrict__ in32, aniels_rec *__restrict__ table, size_t n,
+                                                uint32_t *__restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in32 + 32 * i);
+    uint4 a0 = p[0], a1 = p[1];
+    uint32_t b[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    fe x, y;
+    ge_aniels q;
+    if (ristretto_decode_affine_w(x, y, b)) {
+        ge_affine_to_aniels(q, x, y);
+    } else {
+        ge_aniels_identity(q);
+        atomicAdd(bad, 1u);
+    }
+    store_aniels(table + i, q);
+}
+
+// RistrettoPoint::from_uniform_bytes per thread, normalised to affine Niels
+__global__ void __launch_bounds__(256) k_from_uniform(const uint8_t *__restrict__ in64, aniels_rec *__restrict__ table,
+                                                      size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in64 + 64 * i);
+    uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    uint32_t b[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+    ge P;
+    ristretto_from_uniform_words(P, b);
+    fe zinv;
+    fe_invert(zinv, P.Z);
+    ge_aniels q;
+    ge_to_aniels(q, P, zinv);
+    store_aniels(table + i, q);
+}
+
+// RistrettoPoint::compress of table entries
+__global__ void __launch_bounds__(256) k_compress(const aniels_rec *__restrict__ table, uint8_t *__restrict__ out32, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *w = table[i].w;
+    fe yp, ym, inv2, x, y;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        yp.v[k] = w[k];
+        ym.v[k] = w[8 + k];
+        inv2.v[k] = 0xffffffffu;
+    }
+    inv2.v[0] = 0xfffffff7u;
+    inv2.v[7] = 0x3fffffffu;          // (p+1)/2
+    fe_sub(x, yp, ym);
+    fe_add(y, yp, ym);
+    fe_mul(x, x, inv2);
+    fe_mul(y, y, inv2);
+    ge P;
+    P.X = x;
+    P.Y = y;
+    fe_set1(P.Z);
+    fe_mul(P.T, x, y);
+    uint32_t b[8];
+    ristretto_encode_w(b, P);
+    uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * i);
+    o[0] = make_uint4(b[0], b[1], b[2], b[3]);
+    o[1] = make_uint4(b[4], b[5], b[6], b[7]);
+}
+
+}  // namespace bpg
+
+using namespace bpg;
+
+extern "C" {
+
+const char *bpg_last_error(void) { return bpg::g_err; }
+const char *bpg_version(void) { return "bulletproofs_gadgets_amd 0.1 (gfx950)"; }
+
+int bpg_init(int device_id, bpg_ctx **out) {
+    if (!out) return BPG_EINVAL;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_last_error_msg("bpg_init: no HIP device visible (this library has no CPU fallback)");
+        return BPG_EDEVICE;
+    }
+    if (device_id < 0 || device_id >= count) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(device_id));
+    bpg_ctx *ctx = new bpg_ctx();
+    ctx->device = device_id;
+    BPG_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (const char *s = getenv("BPG_MSM_C")) ctx->force_c = atoi(s);
+    if (const char *s = getenv("BPG_MSM_P")) ctx->force_p = atoi(s);
+    *out = ctx;
+    return BPG_OK;
+}
+
+void bpg_shutdown(bpg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto *j : ctx->jobs) msm_job_destroy(j);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int bpg_device_alloc(bpg_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_CHECK_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return BPG_OK;
+}
+int bpg_device_free(bpg_ctx *ctx, void *d_ptr) {
+    if (!ctx) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipFree(d_ptr));
+    return BPG_OK;
+}
+int bpg_copy_to_device(bpg_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return BPG_OK;
+}
+int bpg_copy_to_host(bpg_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return BPG_OK;
+}
+int bpg_synchronize(bpg_ctx *ctx) {
+    if (!ctx) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_CHECK_HIP(hipDeviceSynchronize());
+    return BPG_OK;
+}
+
+static int points_alloc(bpg_ctx *ctx, size_t n, bpg_points **out) {
+    bpg_points *p = new bpg_points();
+    p->ctx = ctx;
+    p->n = n;
+    p->d_table = nullptr;
+    hipError_t e = hipMalloc((void **)&p->d_table, (n ? n : 1) * sizeof(aniels_rec));
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc(point table)", e);
+        delete p;
+        return BPG_ENOMEM;
+    }
+    *out = p;
+    return BPG_OK;
+}
+
+int bpg_points_from_compressed(bpg_ctx *ctx, const uint8_t *points32, size_t n, bpg_points **out) {
+    if (!ctx || !out || (n && !points32)) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    bpg_points *p = nullptr;
+    int rc = points_alloc(ctx, n, &p);
+    if (rc) return rc;
+    if (n) {
+        uint8_t *d_in = nullptr;
+        uint32_t *d_bad = nullptr;
+        uint32_t bad = 0;
+        BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
+        BPG_CHECK_HIP(hipMalloc((void **)&d_bad, 4));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_in, points32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        BPG_CHECK_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, p->d_table, n, d_bad);
+        BPG_CHECK_HIP(hipGetLastError());
+        BPG_CHECK_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_in);
+        (void)hipFree(d_bad);
+        if (bad) {
+            bpg_points_free(p);
+            set_last_error_msg("bpg_points_from_compressed: invalid ristretto255 encoding");
+            return BPG_EFORMAT;
+        }
+    }
+    *out = p;
+    return BPG_OK;
+}
+
+int bpg_points_from_uniform(bpg_ctx *ctx, const uint8_t *uniform64, size_t n, bpg_points **out) {
+    if (!ctx || !out || (n && !uniform64)) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    bpg_points *p = nullptr;
+    int rc = points_alloc(ctx, n, &p);
+    if (rc) return rc;
+    if (n) {
+        uint8_t *d_in = nullptr;
+        BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_in, uniform64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, p->d_table, n);
+        BPG_CHECK_HIP(hipGetLastError());
+        BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_in);
+    }
+    *out = p;
+    return BPG_OK;
+}
+
+int bpg_points_compress(bpg_ctx *ctx, const bpg_points *pts, size_t start, size_t n, uint8_t *out32) {
+    if (!ctx || !pts || (n && !out32) || start + n > pts->n) return BPG_EINVAL;
+    if (!n) return BPG_OK;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    uint8_t *d_out = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_out, n * 32));
+    hipLaunchKernelGGL(k_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pts->d_table + start, d_out, n);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipMemcpyAsync(out32, d_out, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_out);
+    return BPG_OK;
+}
+
+size_t bpg_points_len(const bpg_points *pts) { return pts ? pts->n : 0; }
+
+void bpg_points_free(bpg_points *pts) {
+    if (!pts) return;
+    (void)hipFree(pts->d_table);
+    delete pts;
+}
+
+int bpg_msm_submit_segments(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len,
+                            size_t n_segments, const void *d_scalars, size_t n_targets, bpg_msm_job **job) {
+    if (!seg_start || !seg_len || n_segments < 1 || n_segments > 4 || n_targets < 1 || n_targets > 65535) return BPG_EINVAL;
+    size_t n = 0;
+    for (size_t k = 0; k < n_segments; k++) n += seg_len[k];
+    return msm_submit(ctx, pts, seg_start, seg_len, (int)n_segments, d_scalars, n, (int)n_targets, false, job);
+}
+
+int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, size_t n, size_t n_targets, bpg_msm_job **job) {
+    if (n_targets < 1 || n_targets > 65535) return BPG_EINVAL;
+    size_t start = 0, len = n;
+    return msm_submit(ctx, pts, &start, &len, 1, d_scalars, n, (int)n_targets, false, job);
+}
+
+int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32) { return msm_wait(job, out32); }
+
+int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_t n, uint8_t out32[32]) {
+    if (!ctx || !pts || !out32 || (n && !scalars32)) return BPG_EINVAL;
+    size_t start = 0, len = n;
+    bpg_msm_job *job = nullptr;
+    int rc = msm_submit(ctx, pts, &start, &len, 1, scalars32, n, 1, true, &job);
+    if (rc) {
+        if (job) job->busy = false;
+        return rc;
+    }
+    return msm_wait(job, out32);
+}
+
+int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int *windows, int *buckets, int *threads_per_bucket) {
+    if (!ctx) return BPG_EINVAL;
+    msm_plan pl = make_plan(n, (int)n_targets, ctx->force_c);
+    if (ctx->force_p >= 1 && ctx->force_p <= 64 && (ctx->force_p & (ctx->force_p - 1)) == 0) pl.P = ctx->force_p;
+    if (window_bits) *window_bits = pl.c;
+    if (windows) *windows = pl.W;
+    if (buckets) *buckets = pl.NB;
+    if (threads_per_bucket) *threads_per_bucket = pl.P;
+    return BPG_OK;
+}
+
+int bpg_msm_last_kernel_us(bpg_ctx *ctx, float *accumulate_us, float *total_device_us) {
+    if (!ctx) return BPG_EINVAL;
+    if (accumulate_us) *accumulate_us = ctx->last_acc_us;
+    if (total_device_us) *total_device_us = ctx->last_total_us;
+    return BPG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// bpg_internal.h -- shared declarations of the MI355X product library (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/bpg.h"
+#include "ge25519.h"
+#include "sc25519.h"
+
+namespace bpg {
+
+// One resident table entry: affine Niels point, 96 B used, padded to one 128-B line.
+struct alignas(16) aniels_rec {
+    uint32_t w[32];   // [0..8) y+x, [8..16) y-x, [16..24) 2dxy, [24..32) unused
+};
+static_assert(sizeof(aniels_rec) == 128, "table stride is one cache line");
+
+// Extended point as stored in HBM work buffers (128 B): X, Y, Z, T.
+struct alignas(16) ge_rec {
+    uint32_t w[32];
+};
+
+void set_last_error(const char *what, hipError_t e);
+void set_last_error_msg(const char *what);
+
+#define BPG_CHECK_HIP(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) {                               \
+            bpg::set_last_error(#expr, _e);                   \
+            return BPG_EDEVICE;                               \
+        }                                                     \
+    } while (0)
+
+// Geometry of one Pippenger run.
+struct msm_plan {
+    int c;            // window bits
+    int W;            // windows = 255 / c + 1
+    int NB;           // buckets per window = 2^(c-1)
+    int P;            // threads (partial sums) per bucket
+    int tile;         // scalars per histogram tile
+    int ntiles;
+    size_t n;         // scalars per target
+    int T;            // targets
+    int chunk;        // buckets per tail-A block = min(256, NB)
+    int nchunks;      // NB / chunk
+    int outs;         // points per (target, window) = c  (total + c-1 bit sums)
+};
+msm_plan make_plan(size_t n, int T, int force_c);
+
+int grow(void **p, size_t *cap, size_t need);
+
+inline void ge_load(ge &p, const ge_rec &r) {
+    for (int i = 0; i < 8; i++) {
+        p.X.v[i] = r.w[i];
+        p.Y.v[i] = r.w[8 + i];
+        p.Z.v[i] = r.w[16 + i];
+        p.T.v[i] = r.w[24 + i];
+    }
+}
+
+}  // namespace bpg
+
+struct bpg_points {
+    bpg_ctx *ctx;
+    bpg::aniels_rec *d_table;
+    size_t n;
+};
+
+// Device workspace + stream of one in-flight MSM.
+struct bpg_msm_job {
+    bpg_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, acc begin, acc end, end
+    bpg::msm_plan plan{};
+    int16_t *d_digits = nullptr;      size_t cap_digits = 0;
+    uint32_t *d_entries = nullptr;    size_t cap_entries = 0;
+    uint32_t *d_counts = nullptr;     size_t cap_counts = 0;
+    bpg::ge_rec *d_partials = nullptr; size_t cap_partials = 0;
+    bpg::ge_rec *d_chunk = nullptr;   size_t cap_chunk = 0;
+    bpg::ge_rec *d_out = nullptr;     size_t cap_out = 0;
+    bpg::ge_rec *h_out = nullptr;     size_t cap_hout = 0;      // pinned host
+    void *d_stage = nullptr;          size_t cap_stage = 0;     // scalars staged from the host
+    bool busy = false;
+};
+
+struct bpg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;     // setup / codec stream
+    std::vector<bpg_msm_job *> jobs;
+    int force_c = 0;                  // BPG_MSM_C env override (tuning)
+    int force_p = 0;                  // BPG_MSM_P env override (tuning)
+    float last_acc_us = 0.f, last_total_us = 0.f;
+};
+
+namespace bpg {
+int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
+               const void *scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job);
+int msm_wait(bpg_msm_job *job, uint8_t *out32);
+void msm_job_destroy(bpg_msm_job *job);
+}  // namespace bpg

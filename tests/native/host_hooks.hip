@@ -1,0 +1,61 @@
+// tests/native/host_hooks.hip -- TEST-ONLY shared library.
+// Exposes the HOST instantiation of the product's host+device arithmetic
+// headers (fe25519.h / sc25519.h / ge25519.h) so that the CPU test-suite can
+// check the exact source the GPU kernels are built from against Python big
+// integers and the oracle, without a GPU.  No HIP runtime call is made here.
+#include <cstring>
+#include "../../bulletproofs_gadgets_amd/csrc/ge25519.h"
+#include "../../bulletproofs_gadgets_amd/csrc/sc25519.h"
+
+using namespace bpg;
+
+static void fe_in(fe &r, const uint8_t *b) {
+    for (int i = 0; i < 8; i++)
+        r.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+}
+static void sc_in(sc &r, const uint8_t *b) { sc_frombytes(r, b); }
+
+extern "C" {
+
+// raw 256-bit in (weakly reduced inputs allowed), canonical 32 bytes out
+void hh_fe_mul(uint8_t *out, const uint8_t *a, const uint8_t *b) { fe x, y, r; fe_in(x, a); fe_in(y, b); fe_mul(r, x, y); fe_tobytes(out, r); }
+void hh_fe_sq(uint8_t *out, const uint8_t *a) { fe x, r; fe_in(x, a); fe_sq(r, x); fe_tobytes(out, r); }
+void hh_fe_add(uint8_t *out, const uint8_t *a, const uint8_t *b) { fe x, y, r; fe_in(x, a); fe_in(y, b); fe_add(r, x, y); fe_tobytes(out, r); }
+void hh_fe_sub(uint8_t *out, const uint8_t *a, const uint8_t *b) { fe x, y, r; fe_in(x, a); fe_in(y, b); fe_sub(r, x, y); fe_tobytes(out, r); }
+void hh_fe_mul_small(uint8_t *out, const uint8_t *a, uint32_t s) { fe x, r; fe_in(x, a); fe_mul_small(r, x, s); fe_tobytes(out, r); }
+void hh_fe_invert(uint8_t *out, const uint8_t *a) { fe x, r; fe_in(x, a); fe_invert(r, x); fe_tobytes(out, r); }
+// raw (un-canonicalised) limbs of a product, to test the weak-reduction invariant
+void hh_fe_mul_raw(uint8_t *out, const uint8_t *a, const uint8_t *b) { fe x, y, r; fe_in(x, a); fe_in(y, b); fe_mul(r, x, y); memcpy(out, r.v, 32); }
+
+void hh_sc_mul(uint8_t *out, const uint8_t *a, const uint8_t *b) { sc x, y, r; sc_in(x, a); sc_in(y, b); sc_mul(r, x, y); sc_tobytes(out, r); }
+void hh_sc_add(uint8_t *out, const uint8_t *a, const uint8_t *b) { sc x, y, r; sc_in(x, a); sc_in(y, b); sc_add(r, x, y); sc_tobytes(out, r); }
+void hh_sc_sub(uint8_t *out, const uint8_t *a, const uint8_t *b) { sc x, y, r; sc_in(x, a); sc_in(y, b); sc_sub(r, x, y); sc_tobytes(out, r); }
+void hh_sc_invert(uint8_t *out, const uint8_t *a) { sc x, r; sc_in(x, a); sc_invert(r, x); sc_tobytes(out, r); }
+void hh_sc_reduce256(uint8_t *out, const uint8_t *a) { sc x, r; sc_in(x, a); sc_reduce256(r, x); sc_tobytes(out, r); }
+void hh_sc_reduce512(uint8_t *out, const uint8_t *a) { sc lo, hi, r; sc_in(lo, a); sc_in(hi, a + 32); sc_reduce512(r, lo, hi); sc_tobytes(out, r); }
+
+int hh_ristretto_decode_encode(uint8_t *out, const uint8_t *in) {
+    ge p;
+    if (!ristretto_decode(p, in)) return -1;
+    ristretto_encode(out, p);
+    return 0;
+}
+void hh_from_uniform(uint8_t *out, const uint8_t *in64) { ge p; ristretto_from_uniform_bytes(p, in64); ristretto_encode(out, p); }
+// out = compress(2*P + Q) through double / add / madd paths
+int hh_group_ops(uint8_t *out_dbl_add, uint8_t *out_madd, uint8_t *out_msub, const uint8_t *P32, const uint8_t *Q32) {
+    ge p, q, r;
+    fe qx, qy;
+    if (!ristretto_decode(p, P32) || !ristretto_decode_affine(qx, qy, Q32)) return -1;
+    q.X = qx; q.Y = qy; fe_set1(q.Z); fe_mul(q.T, qx, qy);
+    ge_double(r, p);
+    ge_add(r, r, q);
+    ristretto_encode(out_dbl_add, r);
+    ge_aniels n;
+    ge_affine_to_aniels(n, qx, qy);
+    ge_madd(r, p, n, false);
+    ristretto_encode(out_madd, r);
+    ge_madd(r, p, n, true);
+    ristretto_encode(out_msub, r);
+    return 0;
+}
+}

@@ -1,0 +1,128 @@
+"""GPU parity tests of the MSM path (BASELINE config 2: raw Ristretto255 MSM,
+bit-exact vs the dalek schedules restated in oracle/msm.c).  Through the C ABI.
+
+Integer work: the bar is byte equality of the 32-byte compressed result.
+"""
+import hashlib
+
+import pytest
+
+from bulletproofs_gadgets_amd import synth
+from bulletproofs_gadgets_amd._native import BpgError, EFORMAT
+
+pytestmark = pytest.mark.gpu
+
+L = synth.L
+
+
+def _scalars_from_ints(vals):
+    return b"".join(int(v % L).to_bytes(32, "little") for v in vals)
+
+
+@pytest.fixture(scope="module")
+def table(gpu_ctx, oracle):
+    """4096 uniform points resident on the GPU + the same points in the oracle."""
+    n = 4096
+    u = synth.uniform_bytes(n, tag=b"P")
+    pts = gpu_ctx.points_from_uniform(u)
+    arr, _ = oracle.from_uniform(u)
+    return pts, arr, n
+
+
+def test_elligator_table_matches_oracle(gpu_ctx, oracle, table):
+    pts, arr, n = table
+    assert pts.compress(0, n) == oracle.encode(arr, n)
+
+
+def test_decode_table_roundtrip(gpu_ctx, oracle, table):
+    pts, arr, n = table
+    enc = oracle.encode(arr, 512)
+    t2 = gpu_ctx.points_from_compressed(enc)
+    assert t2.compress() == enc
+
+
+def test_decode_rejects_invalid(gpu_ctx):
+    p = 2**255 - 19
+    good = bytes(32)  # identity encoding is valid
+    for bad in [p.to_bytes(32, "little"), (1).to_bytes(32, "little"), bytes([0xff] * 32), (2**255).to_bytes(32, "little")]:
+        with pytest.raises(BpgError) as e:
+            gpu_ctx.points_from_compressed(good + bad + good)
+        assert e.value.code == EFORMAT
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 64, 189, 190, 499, 500, 799, 800, 1024, 4096])
+def test_msm_matches_oracle(gpu_ctx, oracle, table, n):
+    pts, arr, _ = table
+    sc = synth.scalars(n, tag=b"s%d" % n)
+    got = gpu_ctx.msm(pts, sc)
+    want = oracle.msm(sc, arr, n)
+    assert got == want
+
+
+def test_msm_edge_scalars(gpu_ctx, oracle, table):
+    pts, arr, _ = table
+    vals = [0, 1, L - 1, 2, L - 2, 2**252, 2**252 - 1, (L - 1) // 2, (L + 1) // 2, 2**13, 2**13 - 1, 2**14, 2**64 - 1,
+            0, 0, 1, 1] + [2**k for k in range(0, 252, 9)] + [2**k - 1 for k in range(1, 252, 11)]
+    sc = _scalars_from_ints(vals)
+    n = len(vals)
+    assert gpu_ctx.msm(pts, sc) == oracle.msm(sc, arr, n)
+    # all-zero scalars -> identity
+    assert gpu_ctx.msm(pts, bytes(32 * 100)) == bytes(32)
+
+
+def test_msm_repeated_and_negated_points(gpu_ctx, oracle):
+    # P, P, -P style cancellations: s*P + (l-s)*P = identity
+    u = synth.uniform_bytes(1, tag=b"rep") * 8
+    pts = gpu_ctx.points_from_uniform(u)
+    s = int.from_bytes(hashlib.sha256(b"s").digest(), "little") % L
+    sc = _scalars_from_ints([s, L - s, 5, L - 5, 0, 0, 7, L - 7])
+    assert gpu_ctx.msm(pts, sc) == bytes(32)
+    arr, _ = oracle.from_uniform(u)
+    sc2 = _scalars_from_ints([s, s, 5, 5, 1, 2, 3, 4])
+    assert gpu_ctx.msm(pts, sc2) == oracle.msm(sc2, arr, 8)
+
+
+def test_msm_skewed_witness_scalars(gpu_ctx, oracle, table):
+    """a_L / a_R in the gadget circuits are mostly bits and small values."""
+    pts, arr, n = table
+    sc = synth.small_scalars(n, 1, tag=b"bits")
+    assert gpu_ctx.msm(pts, sc) == oracle.msm(sc, arr, n)
+    sc = synth.small_scalars(n, 20, tag=b"small")
+    assert gpu_ctx.msm(pts, sc) == oracle.msm(sc, arr, n)
+
+
+def test_msm_multi_target_segments(gpu_ctx, oracle, table):
+    pts, arr, n = table
+    # 3 targets over segments [100,100+300) ++ [2000,2000+212) ++ [4095,4096)
+    segs = [(100, 300), (2000, 212), (4095, 1)]
+    m = sum(l for _, l in segs)
+    sc = synth.scalars(3 * m, tag=b"mt")
+    buf = gpu_ctx.alloc(len(sc)).upload(sc)
+    got = gpu_ctx.msm_submit(pts, buf.ptr, m, 3, segments=segs).wait()
+    sub, cnt = oracle.concat(*[(oracle.slice(arr, s, l), l) for s, l in segs])
+    for t in range(3):
+        want = oracle.msm(sc[32 * m * t:32 * m * (t + 1)], sub, cnt)
+        assert got[32 * t:32 * t + 32] == want
+
+
+def test_msm_two_jobs_in_flight(gpu_ctx, oracle, table):
+    pts, arr, n = table
+    s1, s2 = synth.scalars(n, tag=b"j1"), synth.scalars(n, tag=b"j2")
+    b1, b2 = gpu_ctx.alloc(len(s1)).upload(s1), gpu_ctx.alloc(len(s2)).upload(s2)
+    j1 = gpu_ctx.msm_submit(pts, b1.ptr, n)
+    j2 = gpu_ctx.msm_submit(pts, b2.ptr, n)
+    assert j2.wait() == oracle.msm(s2, arr, n)
+    assert j1.wait() == oracle.msm(s1, arr, n)
+
+
+def test_msm_linearity_at_size(gpu_ctx):
+    """Size-independent property at 2^16: MSM(a) + MSM(b) == MSM(a+b) via a 2-point MSM of the results."""
+    n = 1 << 16
+    pts = gpu_ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"big"))
+    a, b = synth.scalars(n, tag=b"la"), synth.scalars(n, tag=b"lb")
+    ab = b"".join(((int.from_bytes(a[32 * i:32 * i + 32], "little") + int.from_bytes(b[32 * i:32 * i + 32], "little")) % L)
+                  .to_bytes(32, "little") for i in range(n))
+    ra, rb, rab = gpu_ctx.msm(pts, a), gpu_ctx.msm(pts, b), gpu_ctx.msm(pts, ab)
+    two = gpu_ctx.points_from_compressed(ra + rb)
+    one = (1).to_bytes(32, "little")
+    assert gpu_ctx.msm(two, one + one) == rab

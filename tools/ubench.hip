@@ -1,0 +1,213 @@
+// tools/ubench.hip -- integer-VALU microbenchmarks for gfx950.
+// Measures the sustained rate of the instructions the field arithmetic is
+// built from (v_mad_u64_u32, v_mul_lo/hi_u32, v_add_co/v_addc_co, v_fma_f64) and
+// of whole field operations (fe_mul, fe_sq, mixed addition), so that the MSM
+// roofline has a measured denominator.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../bulletproofs_gadgets_amd/csrc/ge25519.h"
+
+using namespace bpg;
+
+#define CHECK(x)                                                                   \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                 \
+            exit(1);                                                               \
+        }                                                                          \
+    } while (0)
+
+constexpr int ITERS = 512;
+
+// 8 independent mad chains per lane
+__global__ void __launch_bounds__(256) k_mad64(uint64_t *out, uint32_t a, uint32_t b) {
+    uint64_t acc[8];
+    uint32_t x = a + threadIdx.x, y = b + blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (uint64_t)x * y + acc[k];
+        x ^= (uint32_t)acc[0];   // keep operands live / varying
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mullo(uint32_t *out, uint32_t a) {
+    uint32_t acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = a + k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = acc[k] * acc[k] + 1u;   // v_mul_lo_u32 + add (or v_mad_u32?)
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mulhi(uint32_t *out, uint32_t a) {
+    uint32_t acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = a + k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = __umulhi(acc[k], 0x9e3779b9u + k) ^ a;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_addc(uint32_t *out, uint32_t a) {
+    uint32_t acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = a + k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = addc32(acc[k], a, c, c);
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_add32(uint32_t *out, uint32_t a) {
+    uint32_t acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = a + k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = (acc[k] + a) ^ (acc[(k + 1) & 7]);   // 2 simple ops
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_dfma(double *out, double a, double b) {
+    double acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = a + k + threadIdx.x;
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = __builtin_fma(acc[k], b, a);
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += acc[k];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_femul(fe *out, const fe *in) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    fe x = in[i], y = in[i + 1];
+    for (int k = 0; k < ITERS / 2; k++) {
+        fe_mul(x, x, y);
+        fe_mul(y, y, x);
+    }
+    out[i] = x;
+    out[i + 1] = y;
+}
+
+__global__ void __launch_bounds__(256) k_fesq(fe *out, const fe *in) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    fe x = in[i], y = in[i + 1];
+    for (int k = 0; k < ITERS / 2; k++) {
+        fe_sq(x, x);
+        fe_sq(y, y);
+    }
+    out[i] = x;
+    out[i + 1] = y;
+}
+
+__global__ void __launch_bounds__(256) k_madd(fe *out, const fe *in) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    ge acc;
+    ge_identity(acc);
+    ge_aniels q;
+    q.YpX = in[i];
+    q.YmX = in[i + 1];
+    q.T2d = in[i + 2];
+    for (int k = 0; k < ITERS / 8; k++) ge_madd(acc, acc, q, (k & 1) != 0);
+    out[i] = acc.X;
+    out[i + 1] = acc.Y;
+    out[i + 2] = acc.Z;
+    out[i + 3] = acc.T;
+}
+
+template <typename F>
+static double time_ms(F launch, int reps = 5) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(a));
+        launch();
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main(int argc, char **argv) {
+    int blocks_per_cu = argc > 1 ? atoi(argv[1]) : 8;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    int blocks = cus * blocks_per_cu;
+    size_t nthreads = (size_t)blocks * 256;
+    void *buf, *in;
+    CHECK(hipMalloc(&buf, nthreads * 64 + 4096));
+    CHECK(hipMalloc(&in, nthreads * 32 + 4096));
+    std::vector<uint32_t> h((nthreads * 32 + 4096) / 4);
+    uint32_t s = 12345;
+    for (auto &x : h) {
+        s = s * 1664525u + 1013904223u;
+        x = s;
+    }
+    CHECK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, \"blocks_per_cu\": %d,\n", prop.gcnArchName, cus,
+           prop.clockRate / 1000, blocks_per_cu);
+    double ms;
+    const double lanes = (double)nthreads;
+    ms = time_ms([&] { hipLaunchKernelGGL(k_mad64, dim3(blocks), dim3(256), 0, 0, (uint64_t *)buf, 3u, 5u); });
+    printf(" \"v_mad_u64_u32_Gops\": %.1f,\n", lanes * ITERS * 8 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_mullo, dim3(blocks), dim3(256), 0, 0, (uint32_t *)buf, 3u); });
+    printf(" \"mul_lo_plus_add_Gops\": %.1f,\n", lanes * ITERS * 8 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_mulhi, dim3(blocks), dim3(256), 0, 0, (uint32_t *)buf, 3u); });
+    printf(" \"mul_hi_plus_xor_Gops\": %.1f,\n", lanes * ITERS * 8 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_addc, dim3(blocks), dim3(256), 0, 0, (uint32_t *)buf, 3u); });
+    printf(" \"v_addc_chain_Gops\": %.1f,\n", lanes * ITERS * 8 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_add32, dim3(blocks), dim3(256), 0, 0, (uint32_t *)buf, 3u); });
+    printf(" \"simple_int32_Gops\": %.1f,\n", lanes * ITERS * 16 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_dfma, dim3(blocks), dim3(256), 0, 0, (double *)buf, 1.0000001, 0.9999999); });
+    printf(" \"v_fma_f64_Gops\": %.1f,\n", lanes * ITERS * 8 / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_femul, dim3(blocks), dim3(256), 0, 0, (fe *)buf, (const fe *)in); });
+    printf(" \"fe_mul_G\": %.2f,\n", lanes * ITERS / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_fesq, dim3(blocks), dim3(256), 0, 0, (fe *)buf, (const fe *)in); });
+    printf(" \"fe_sq_G\": %.2f,\n", lanes * ITERS / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_madd, dim3(blocks), dim3(256), 0, 0, (fe *)buf, (const fe *)in); });
+    printf(" \"ge_madd_G\": %.3f\n}\n", lanes * (ITERS / 8) / ms / 1e6);
+    return 0;
+}
