@@ -276,7 +276,6 @@ int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_
 int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int *windows, int *buckets, int *threads_per_bucket) {
     if (!ctx) return BPG_EINVAL;
     msm_plan pl = make_plan(n, (int)n_targets, ctx->force_c);
-    if (ctx->force_p >= 1 && ctx->force_p <= 64 && (ctx->force_p & (ctx->force_p - 1)) == 0) pl.P = ctx->force_p;
     if (window_bits) *window_bits = pl.c;
     if (windows) *windows = pl.W;
     if (buckets) *buckets = pl.NB;

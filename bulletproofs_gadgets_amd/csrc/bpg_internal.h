@@ -40,7 +40,9 @@ struct msm_plan {
     int c;            // window bits
     int W;            // windows = 255 / c + 1
     int NB;           // buckets per window = 2^(c-1)
-    int P;            // threads (partial sums) per bucket
+    int P;            // entries per accumulate thread = 2^ls0
+    int ls0, ls1;     // log2 of the segment sizes: S0 entries / thread, S1 partials / merge thread
+    int R;            // reduction passes after the accumulate pass
     int tile;         // scalars per histogram tile
     int ntiles;
     size_t n;         // scalars per target

@@ -165,16 +165,37 @@ __global__ void __launch_bounds__(512) k_hist(const int16_t *__restrict__ digits
     }
 }
 
-// exclusive scan, phase A: 1024 elements per block -> local offsets + block total
+// Segment counts.  A bucket with `cnt` entries is summed by ceil(cnt / S0)
+// threads (level 0), whose partial sums are merged S1 at a time by the
+// reduction passes (levels 1..R) until one sum per bucket is left.  This keeps
+// every thread's work bounded whatever the digit distribution is: the signed
+// recoding sends ~n/2 carries to one bucket of the top window, and gadget
+// witnesses (bits, small values) pile up in a few low buckets.
+//   level -1: cnt            level 0: ceil(cnt/S0)           level r: ceil(level r-1 / S1)
+__device__ __forceinline__ uint32_t seg_count(uint32_t cnt, int level, int ls0, int ls1) {
+    if (level < 0) return cnt;
+    uint32_t x = (cnt + (1u << ls0) - 1) >> ls0;
+    for (int i = 0; i < level; i++) x = (x + (1u << ls1) - 1) >> ls1;
+    return x;
+}
+// number of threads a bucket contributes to pass `level`: passes >= 1 only touch
+// buckets that still have more than one partial
+__device__ __forceinline__ uint32_t pass_threads(uint32_t cnt, int level, int ls0, int ls1) {
+    if (level <= 0) return seg_count(cnt, level, ls0, ls1);
+    uint32_t prev = seg_count(cnt, level - 1, ls0, ls1);
+    return prev > 1 ? ((prev + (1u << ls1) - 1) >> ls1) : 0u;
+}
+
+// exclusive scan, phase A: 1024 elements per block -> local offsets + block total.
+// The scanned value is pass_threads(counts[i], level).
 __global__ void __launch_bounds__(256) k_scan_a(const uint32_t *__restrict__ counts, uint32_t *__restrict__ local,
-                                                uint32_t *__restrict__ totals, size_t ne) {
+                                                uint32_t *__restrict__ totals, size_t ne, int level, int ls0, int ls1) {
     __shared__ uint32_t wsum[4];
     size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
     uint32_t v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = (base + k < ne) ? counts[base + k] : 0u;
+    for (int k = 0; k < 4; k++) v[k] = (base + k < ne) ? pass_threads(counts[base + k], level, ls0, ls1) : 0u;
     uint32_t mine = v[0] + v[1] + v[2] + v[3];
-    // wave inclusive scan
     uint32_t x = mine;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -195,7 +216,8 @@ __global__ void __launch_bounds__(256) k_scan_a(const uint32_t *__restrict__ cou
     if (threadIdx.x == 255) totals[blockIdx.x] = wbase + x;
 }
 
-// exclusive scan, phase B: block totals -> block bases (single block, loops)
+// exclusive scan, phase B: block totals -> block bases (single block, loops);
+// totals[nblk] receives the grand total.
 __global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ totals, size_t nblk) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t running;
@@ -220,6 +242,7 @@ __global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ totals, 
         if (threadIdx.x == 1023) running = wbase + x;
         __syncthreads();
     }
+    if (threadIdx.x == 0) totals[nblk] = running;
 }
 
 // bucket-sorted entry list.  entries[pos] = scalar index | sign << 31
@@ -268,47 +291,111 @@ __device__ __forceinline__ uint32_t map_index(const seg_map &m, uint32_t i) {
     return r;
 }
 
-// THE hot kernel: P threads per bucket, each sums its share of the bucket's
-// entries with 7M mixed additions.  Integer-VALU bound (v_mad_u64_u32 chains).
-__global__ void __launch_bounds__(256) k_accumulate(const aniels_rec *__restrict__ table, const uint32_t *__restrict__ entries,
-                                                    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ local,
-                                                    const uint32_t *__restrict__ blockbase, ge_rec *__restrict__ partials,
-                                                    size_t nthreads, int logP, seg_map map) {
-    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= nthreads) return;
-    size_t g = gid >> logP;
-    uint32_t p = (uint32_t)(gid & ((1u << logP) - 1));
-    uint32_t cnt = counts[g];
-    uint32_t off = local[g] + blockbase[g >> 10];
-    uint32_t lo = off + (uint32_t)(((uint64_t)cnt * p) >> logP);
-    uint32_t hi = off + (uint32_t)(((uint64_t)cnt * (p + 1)) >> logP);
-    ge acc;
-    ge_identity(acc);
-    for (uint32_t e = lo; e < hi; e++) {
-        uint32_t ent = entries[e];
-        ge_aniels q;
-        load_aniels(q, table + map_index(map, ent & 0x7fffffffu));
-        ge_madd(acc, acc, q, (ent >> 31) != 0);
+// One scanned level: offsets = local[g] + base[g >> 10]; base[nblk] = total.
+struct level_ref {
+    const uint32_t *local;
+    const uint32_t *base;
+};
+
+// bucket g with off(g) <= t < off(g+1), by a two-level binary search
+__device__ __forceinline__ uint32_t find_bucket(const level_ref &lv, uint32_t t, uint32_t nblk, uint32_t ne, uint32_t &rank) {
+    uint32_t lo = 0, hi = nblk;              // first block j with base[j] > t
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (lv.base[mid] > t) hi = mid; else lo = mid + 1;
     }
-    store_ge(partials + gid, acc);
+    uint32_t j = lo - 1;
+    uint32_t tt = t - lv.base[j];
+    uint32_t s = j << 10, e = s + 1024 < ne ? s + 1024 : ne;
+    lo = s; hi = e;                          // first g in block with local[g] > tt
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (lv.local[mid] > tt) hi = mid; else lo = mid + 1;
+    }
+    uint32_t g = lo - 1;
+    rank = tt - lv.local[g];
+    return g;
 }
 
-// tail A: one block per chunk of `chunk` buckets of one (target, window).
-// Merges the P partials of each bucket, then runs the bit tree; writes
-// log2(chunk)+1 points per chunk.
-__global__ void __launch_bounds__(256) k_tail_a(const ge_rec *__restrict__ partials, ge_rec *__restrict__ out, int NB,
-                                                int chunk, int logchunk, int P, int W) {
+// THE hot kernel.  Thread t owns segment `rank` (S0 entries) of bucket g and sums
+// it with 7M mixed additions.  Integer-VALU bound (v_mad_u64_u32 chains).
+__global__ void __launch_bounds__(256) k_accumulate(const aniels_rec *__restrict__ table, const uint32_t *__restrict__ entries,
+                                                    const uint32_t *__restrict__ counts, level_ref ent, level_ref lv0,
+                                                    ge_rec *__restrict__ parts, uint32_t nblk, uint32_t ne, int ls0,
+                                                    seg_map map) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= lv0.base[nblk]) return;
+    uint32_t rank;
+    uint32_t g = find_bucket(lv0, t, nblk, ne, rank);
+    uint32_t cnt = counts[g];
+    uint32_t off = ent.local[g] + ent.base[g >> 10];
+    uint32_t lo = rank << ls0, hi = lo + (1u << ls0);
+    hi = hi < cnt ? hi : cnt;
+    ge acc;
+    ge_identity(acc);
+    for (uint32_t e = off + lo; e < off + hi; e++) {
+        uint32_t en = entries[e];
+        ge_aniels q;
+        load_aniels(q, table + map_index(map, en & 0x7fffffffu));
+        ge_madd(acc, acc, q, (en >> 31) != 0);
+    }
+    store_ge(parts + t, acc);
+}
+
+// reduction pass `level` (>= 1): thread t merges up to S1 partials of level-1 of its bucket
+__global__ void __launch_bounds__(256) k_reduce(const uint32_t *__restrict__ counts, level_ref prev, level_ref cur,
+                                                const ge_rec *__restrict__ parts_in, ge_rec *__restrict__ parts_out,
+                                                uint32_t nblk, uint32_t ne, int level, int ls0, int ls1) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= cur.base[nblk]) return;
+    uint32_t rank;
+    uint32_t g = find_bucket(cur, t, nblk, ne, rank);
+    uint32_t kprev = seg_count(counts[g], level - 1, ls0, ls1);
+    uint32_t in0 = prev.local[g] + prev.base[g >> 10];
+    uint32_t lo = rank << ls1, hi = lo + (1u << ls1);
+    hi = hi < kprev ? hi : kprev;
+    ge acc;
+    load_ge(acc, parts_in + in0 + lo);
+    for (uint32_t i = lo + 1; i < hi; i++) {
+        ge b;
+        load_ge(b, parts_in + in0 + i);
+        ge_add(acc, acc, b);
+    }
+    store_ge(parts_out + t, acc);
+}
+
+struct levels_dev {
+    level_ref lv[6];
+    const ge_rec *parts[6];
+    int nlevels;          // levels 0 .. nlevels-1 exist
+};
+
+// sum of bucket g: lives at the first level whose segment count is 1
+__device__ __forceinline__ void bucket_sum(ge &acc, const levels_dev &L, const uint32_t *counts, size_t g, int ls0, int ls1) {
+    uint32_t cnt = counts[g];
+    if (cnt == 0) {
+        ge_identity(acc);
+        return;
+    }
+    uint32_t k = (cnt + (1u << ls0) - 1) >> ls0;
+    int r = 0;
+    while (k > 1 && r + 1 < L.nlevels) {
+        k = (k + (1u << ls1) - 1) >> ls1;
+        r++;
+    }
+    load_ge(acc, L.parts[r] + L.lv[r].local[g] + L.lv[r].base[g >> 10]);
+}
+
+// tail A: one block per chunk of `chunk` buckets of one (target, window): bit tree
+// over the bucket index; writes log2(chunk)+1 points per chunk.
+__global__ void __launch_bounds__(256) k_tail_a(levels_dev L, const uint32_t *__restrict__ counts, ge_rec *__restrict__ out,
+                                                int NB, int chunk, int logchunk, int W, int ls0, int ls1) {
     extern __shared__ uint32_t lds[];
     const int cidx = blockIdx.x, w = blockIdx.y, t = blockIdx.z;
     const size_t win = (size_t)t * W + w;
     const size_t g = win * NB + (size_t)cidx * chunk + threadIdx.x;
     ge acc;
-    load_ge(acc, partials + g * P);
-    for (int p = 1; p < P; p++) {
-        ge b;
-        load_ge(b, partials + g * P + p);
-        ge_add(acc, acc, b);
-    }
+    bucket_sum(acc, L, counts, g, ls0, ls1);
     lds_put(lds, chunk, threadIdx.x, acc);
     __syncthreads();
     lds_bit_tree(lds, chunk, chunk, 1, logchunk);
@@ -360,10 +447,13 @@ msm_plan make_plan(size_t n, int T, int force_c) {
     pl.c = c;
     pl.W = 255 / c + 1;
     pl.NB = 1 << (c - 1);
-    size_t per_bucket = n / pl.NB;
-    int P = 1;
-    while (P < 64 && per_bucket / (2 * P) >= 16) P *= 2;
-    pl.P = P;
+    pl.ls0 = 4;
+    pl.ls1 = 4;
+    pl.P = 1 << pl.ls0;
+    // passes: S0 * S1^R >= n  (a bucket never holds more than n entries)
+    int R = 0;
+    while (((size_t)1 << (pl.ls0 + pl.ls1 * R)) < n) R++;
+    pl.R = R;
     int tile = 4096;
     while (tile < 32768 && (size_t)tile * 64 < n) tile *= 2;
     pl.tile = tile;
@@ -398,7 +488,7 @@ static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *d
     switch (c) {
 #define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total); break;
         BPG_CASE(2) BPG_CASE(3) BPG_CASE(4) BPG_CASE(5) BPG_CASE(6) BPG_CASE(7) BPG_CASE(8) BPG_CASE(9)
-        BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14) BPG_CASE(15)
+        BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14)
 #undef BPG_CASE
     }
 }
@@ -438,7 +528,7 @@ void msm_job_destroy(bpg_msm_job *j) {
 int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
                const void *d_scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job) {
     if (!ctx || !pts || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
-    if (n >= ((size_t)1 << 31)) return BPG_EINVAL;
+    if (n >= ((size_t)1 << 28)) return BPG_EINVAL;
     seg_map map{};
     {
         size_t acc = 0;
@@ -458,11 +548,14 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
     bpg_msm_job *j = acquire_job(ctx);
     if (!j) return BPG_EDEVICE;
     msm_plan pl = make_plan(n, T, ctx->force_c);
-    if (ctx->force_p >= 1 && ctx->force_p <= 64 && (ctx->force_p & (ctx->force_p - 1)) == 0) pl.P = ctx->force_p;
     j->plan = pl;
     const size_t NE = (size_t)T * pl.W * pl.NB;           // buckets
+    const size_t M = (size_t)T * pl.W * n;                // upper bound on entries
+    if (M >= ((size_t)1 << 32) || NE >= ((size_t)1 << 30)) return BPG_EINVAL;
     const size_t nblk = (NE + 1023) / 1024;
     const int logchunk = ilog2(pl.chunk), lognch = ilog2(pl.nchunks), per0 = logchunk + 1;
+    const int nlevels = pl.R + 1;                          // levels 0..R
+    if (nlevels > 6) return BPG_EINVAL;
     int rc;
     if ((rc = grow((void **)&j->d_out, &j->cap_out, (size_t)T * pl.W * pl.outs * sizeof(ge_rec)))) return rc;
     if ((size_t)T * pl.W * pl.outs * sizeof(ge_rec) > j->cap_hout) {
@@ -483,10 +576,20 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
         BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
         return BPG_OK;
     }
-    if ((rc = grow((void **)&j->d_digits, &j->cap_digits, (size_t)T * pl.W * n * sizeof(int16_t)))) return rc;
-    if ((rc = grow((void **)&j->d_entries, &j->cap_entries, (size_t)T * pl.W * n * sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void **)&j->d_counts, &j->cap_counts, (3 * NE + nblk + 16) * sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void **)&j->d_partials, &j->cap_partials, NE * pl.P * sizeof(ge_rec)))) return rc;
+    // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
+    size_t cap_lv[6], part_off[6], part_total = 0;
+    cap_lv[0] = (M >> pl.ls0) + NE + 1;
+    for (int r = 1; r < nlevels; r++) cap_lv[r] = cap_lv[r - 1] / 2 + 1;
+    for (int r = 0; r < nlevels; r++) {
+        part_off[r] = part_total;
+        part_total += cap_lv[r];
+    }
+    const size_t lvl_words = NE + nblk + 1;                // local[NE] | base[nblk + 1]
+    if ((rc = grow((void **)&j->d_digits, &j->cap_digits, M * sizeof(int16_t)))) return rc;
+    if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void **)&j->d_counts, &j->cap_counts, (2 * NE + (size_t)(nlevels + 1) * lvl_words + 16) * sizeof(uint32_t))))
+        return rc;
+    if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
     if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.W * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
     const uint32_t *d_sc = (const uint32_t *)d_scalars;
     if (scalars_on_host) {
@@ -494,26 +597,45 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
         BPG_CHECK_HIP(hipMemcpyAsync(j->d_stage, d_scalars, (size_t)T * n * 32, hipMemcpyHostToDevice, s));
         d_sc = (const uint32_t *)j->d_stage;
     }
-    uint32_t *counts = j->d_counts, *local = counts + NE, *fill = local + NE, *totals = fill + NE;
-    BPG_CHECK_HIP(hipMemsetAsync(counts, 0, NE * sizeof(uint32_t), s));
-    BPG_CHECK_HIP(hipMemsetAsync(fill, 0, NE * sizeof(uint32_t), s));
+    uint32_t *counts = j->d_counts, *fill = counts + NE;
+    uint32_t *lvl_base = fill + NE;                        // level -1 (entry offsets), then levels 0..R
+    auto lv_local = [&](int idx) { return lvl_base + (size_t)idx * lvl_words; };
+    auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
+    BPG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * NE * sizeof(uint32_t), s));
 
     dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n);
     dim3 tgrid(pl.ntiles, pl.W, T);
     size_t hist_lds = (size_t)pl.NB * sizeof(uint32_t);
     hipLaunchKernelGGL(k_hist, tgrid, dim3(512), hist_lds, s, j->d_digits, counts, n, pl.W, pl.NB, pl.tile);
-    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, local, totals, NE);
-    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, totals, nblk);
-    hipLaunchKernelGGL(k_scatter, tgrid, dim3(512), hist_lds, s, j->d_digits, local, totals, fill, j->d_entries, n, pl.W,
-                       pl.NB, pl.tile);
-    const size_t nthreads = NE * pl.P;
+    // entry offsets (level -1) and level-0 thread offsets
+    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(0), lv_tot(0), NE, -1, pl.ls0, pl.ls1);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(0), nblk);
+    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(1), lv_tot(1), NE, 0, pl.ls0, pl.ls1);
+    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(1), nblk);
+    hipLaunchKernelGGL(k_scatter, tgrid, dim3(512), hist_lds, s, j->d_digits, lv_local(0), lv_tot(0), fill, j->d_entries, n,
+                       pl.W, pl.NB, pl.tile);
+    level_ref ent{lv_local(0), lv_tot(0)};
+    levels_dev L{};
+    L.nlevels = nlevels;
+    for (int r = 0; r < nlevels; r++) {
+        L.lv[r] = level_ref{lv_local(r + 1), lv_tot(r + 1)};
+        L.parts[r] = j->d_partials + part_off[r];
+    }
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, pts->d_table, j->d_entries,
-                       counts, local, totals, j->d_partials, nthreads, ilog2(pl.P), map);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, pts->d_table, j->d_entries,
+                       counts, ent, L.lv[0], j->d_partials + part_off[0], (uint32_t)nblk, (uint32_t)NE, pl.ls0, map);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
+    for (int r = 1; r < nlevels; r++) {
+        hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(r + 1), lv_tot(r + 1), NE, r,
+                           pl.ls0, pl.ls1);
+        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(r + 1), nblk);
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r],
+                           j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
+                           pl.ls0, pl.ls1);
+    }
     ge_rec *a_out = pl.nchunks == 1 ? j->d_out : j->d_chunk;
-    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.W, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, j->d_partials, a_out,
-                       pl.NB, pl.chunk, logchunk, pl.P, pl.W);
+    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.W, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,
+                       pl.chunk, logchunk, pl.W, pl.ls0, pl.ls1);
     if (pl.nchunks > 1)
         hipLaunchKernelGGL(k_tail_b, dim3(pl.W, T), dim3(320), (size_t)pl.nchunks * per0 * 128, s, j->d_chunk, j->d_out,
                            pl.nchunks, lognch, per0, pl.W);
