@@ -60,6 +60,8 @@ def lib():
         "bpg_msm_submit": (ctypes.c_int, [vp, vp, vp, sz, sz, pvp]),
         "bpg_msm_submit_segments": (ctypes.c_int, [vp, vp, psz, psz, sz, vp, sz, pvp]),
         "bpg_msm_wait": (ctypes.c_int, [vp, vp]),
+        "bpg_msm_wait_partial": (ctypes.c_int, [vp, vp]),
+        "bpg_msm_combine_partials": (ctypes.c_int, [cp, sz, vp]),
         "bpg_msm_plan": (ctypes.c_int, [vp, sz, sz, ip, ip, ip, ip]),
         "bpg_msm_last_kernel_us": (ctypes.c_int, [vp, fp, fp]),
     }
@@ -147,6 +149,20 @@ class MsmJob:
         out = ctypes.create_string_buffer(32 * self.n_targets)
         check(lib().bpg_msm_wait(self._h, out))
         return out.raw
+
+    def wait_partial(self):
+        """n_targets x 128 B un-normalised extended points (for point-range sharding)."""
+        out = ctypes.create_string_buffer(128 * self.n_targets)
+        check(lib().bpg_msm_wait_partial(self._h, out))
+        return out.raw
+
+
+def combine_partials(partials128):
+    """compress(sum of 128-byte partial sums), e.g. one per rank after an all-gather."""
+    assert len(partials128) % 128 == 0
+    out = ctypes.create_string_buffer(32)
+    check(lib().bpg_msm_combine_partials(partials128, len(partials128) // 128, out))
+    return out.raw
 
 
 class Context:

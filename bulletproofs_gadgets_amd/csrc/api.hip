@@ -116,8 +116,10 @@ int bpg_init(int device_id, bpg_ctx **out) {
     bpg_ctx *ctx = new bpg_ctx();
     ctx->device = device_id;
     BPG_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    if (const char *s = getenv("BPG_MSM_C")) ctx->force_c = atoi(s);
-    if (const char *s = getenv("BPG_MSM_P")) ctx->force_p = atoi(s);
+    if (const char *s = getenv("BPG_MSM_C")) ctx->tune.c = atoi(s);
+    if (const char *s = getenv("BPG_MSM_TILE")) ctx->tune.tile = atoi(s);
+    if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);
+    if (const char *s = getenv("BPG_MSM_LS1")) ctx->tune.ls1 = atoi(s);
     *out = ctx;
     return BPG_OK;
 }
@@ -259,7 +261,12 @@ int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, s
     return msm_submit(ctx, pts, &start, &len, 1, d_scalars, n, (int)n_targets, false, job);
 }
 
-int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32) { return msm_wait(job, out32); }
+int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32) { return msm_wait(job, out32, false); }
+int bpg_msm_wait_partial(bpg_msm_job *job, uint8_t *out128) { return msm_wait(job, out128, true); }
+int bpg_msm_combine_partials(const uint8_t *partials128, size_t k, uint8_t out32[32]) {
+    if ((k && !partials128) || !out32) return BPG_EINVAL;
+    return combine_partials(partials128, k, out32);
+}
 
 int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_t n, uint8_t out32[32]) {
     if (!ctx || !pts || !out32 || (n && !scalars32)) return BPG_EINVAL;
@@ -270,12 +277,12 @@ int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_
         if (job) job->busy = false;
         return rc;
     }
-    return msm_wait(job, out32);
+    return msm_wait(job, out32, false);
 }
 
 int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int *windows, int *buckets, int *threads_per_bucket) {
     if (!ctx) return BPG_EINVAL;
-    msm_plan pl = make_plan(n, (int)n_targets, ctx->force_c);
+    msm_plan pl = make_plan(n, (int)n_targets, ctx->tune);
     if (window_bits) *window_bits = pl.c;
     if (windows) *windows = pl.W;
     if (buckets) *buckets = pl.NB;

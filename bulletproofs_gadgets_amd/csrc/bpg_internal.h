@@ -51,7 +51,10 @@ struct msm_plan {
     int nchunks;      // NB / chunk
     int outs;         // points per (target, window) = c  (total + c-1 bit sums)
 };
-msm_plan make_plan(size_t n, int T, int force_c);
+struct msm_tuning {
+    int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
+};
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune);
 
 int grow(void **p, size_t *cap, size_t need);
 
@@ -93,14 +96,14 @@ struct bpg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     // setup / codec stream
     std::vector<bpg_msm_job *> jobs;
-    int force_c = 0;                  // BPG_MSM_C env override (tuning)
-    int force_p = 0;                  // BPG_MSM_P env override (tuning)
+    bpg::msm_tuning tune;
     float last_acc_us = 0.f, last_total_us = 0.f;
 };
 
 namespace bpg {
 int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
                const void *scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job);
-int msm_wait(bpg_msm_job *job, uint8_t *out32);
+int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);
+int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]);
 void msm_job_destroy(bpg_msm_job *job);
 }  // namespace bpg

@@ -125,6 +125,21 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + gid * 8);
     uint4 lo4 = sp[0], hi4 = sp[1];
     uint32_t v[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
+    // s > (l-1)/2  ->  use l - s and flip every digit's sign (s*P = (l-s)*(-P)).
+    // Keeps s below 2^251 so the signed recoding never carries into the top
+    // window: for uniform scalars that carry would put ~n/2 entries in one bucket.
+    // Scalars >= l (not canonical) are left as they are.
+    const uint32_t HL[8] = {0x2e7ae9f6u, 0x2c09318du, 0x517bce6bu, 0x0a6f7cefu, 0u, 0u, 0u, 0x08000000u};
+    const uint32_t LL[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};
+    uint32_t bw = 0, nb = 0, ng[8], dummy;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dummy = subb32(HL[k], v[k], bw, bw);     // bw = (s > half)
+    (void)dummy;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ng[k] = subb32(LL[k], v[k], nb, nb);     // nb = (s > l)
+    const bool flip = bw && !nb;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = flip ? ng[k] : v[k];
     int16_t *out = digits + (t * W) * n + i;
     uint32_t carry = 0;
 #pragma unroll
@@ -139,7 +154,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
         raw += carry;
         carry = raw > half ? 1u : 0u;
         int d = (int)raw - (int)(carry << C);
-        out[(size_t)w * n] = (int16_t)d;
+        out[(size_t)w * n] = (int16_t)(flip ? -d : d);
     }
 }
 
@@ -437,7 +452,8 @@ static int ilog2(size_t x) {
     return r;
 }
 
-msm_plan make_plan(size_t n, int T, int force_c) {
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune) {
+    const int force_c = tune.c;
     msm_plan pl{};
     int lg = n > 1 ? ilog2(n - 1) + 1 : 0;   // ceil(log2 n)
     int c = lg - 5;
@@ -447,8 +463,8 @@ msm_plan make_plan(size_t n, int T, int force_c) {
     pl.c = c;
     pl.W = 255 / c + 1;
     pl.NB = 1 << (c - 1);
-    pl.ls0 = 4;
-    pl.ls1 = 4;
+    pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 8) ? tune.ls0 : 4;
+    pl.ls1 = (tune.ls1 >= 1 && tune.ls1 <= 8) ? tune.ls1 : 4;
     pl.P = 1 << pl.ls0;
     // passes: S0 * S1^R >= n  (a bucket never holds more than n entries)
     int R = 0;
@@ -456,6 +472,7 @@ msm_plan make_plan(size_t n, int T, int force_c) {
     pl.R = R;
     int tile = 4096;
     while (tile < 32768 && (size_t)tile * 64 < n) tile *= 2;
+    if (tune.tile >= 512 && tune.tile <= (1 << 20)) tile = tune.tile;
     pl.tile = tile;
     pl.ntiles = (int)((n + tile - 1) / tile);
     if (pl.ntiles < 1) pl.ntiles = 1;
@@ -547,7 +564,7 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
     BPG_CHECK_HIP(hipSetDevice(ctx->device));
     bpg_msm_job *j = acquire_job(ctx);
     if (!j) return BPG_EDEVICE;
-    msm_plan pl = make_plan(n, T, ctx->force_c);
+    msm_plan pl = make_plan(n, T, ctx->tune);
     j->plan = pl;
     const size_t NE = (size_t)T * pl.W * pl.NB;           // buckets
     const size_t M = (size_t)T * pl.W * n;                // upper bound on entries
@@ -645,8 +662,8 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
     return BPG_OK;
 }
 
-int msm_wait(bpg_msm_job *j, uint8_t *out32) {
-    if (!j || !j->busy || !out32) return BPG_EINVAL;
+int msm_wait(bpg_msm_job *j, uint8_t *out, bool partial) {
+    if (!j || !j->busy || !out) return BPG_EINVAL;
     BPG_CHECK_HIP(hipEventSynchronize(j->ev[3]));
     (void)hipEventElapsedTime(&j->ctx->last_acc_us, j->ev[1], j->ev[2]);
     (void)hipEventElapsedTime(&j->ctx->last_total_us, j->ev[0], j->ev[3]);
@@ -674,9 +691,42 @@ int msm_wait(bpg_msm_job *j, uint8_t *out32) {
                 }
             }
         }
-        ristretto_encode(out32 + 32 * t, acc);
+        if (partial) {
+            // un-normalised extended coordinates X | Y | Z | T, 4 x 32 B little-endian
+            fe_tobytes(out + 128 * t, acc.X);
+            fe_tobytes(out + 128 * t + 32, acc.Y);
+            fe_tobytes(out + 128 * t + 64, acc.Z);
+            fe_tobytes(out + 128 * t + 96, acc.T);
+        } else {
+            ristretto_encode(out + 32 * t, acc);
+        }
     }
     j->busy = false;
+    return BPG_OK;
+}
+
+// sum of k partial results (128-B extended points as written by msm_wait(partial)) -> compressed
+int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]) {
+    ge acc;
+    ge_identity(acc);
+    for (size_t i = 0; i < k; i++) {
+        ge p;
+        fe_frombytes(p.X, ext128 + 128 * i);
+        fe_frombytes(p.Y, ext128 + 128 * i + 32);
+        fe_frombytes(p.Z, ext128 + 128 * i + 64);
+        fe_frombytes(p.T, ext128 + 128 * i + 96);
+        // reject anything that is not a curve point with consistent T: -X^2 + Y^2 = Z^2 + d T^2, XY = ZT
+        fe xx, yy, zz, tt, l, r, xy, zt;
+        fe_sq(xx, p.X); fe_sq(yy, p.Y); fe_sq(zz, p.Z); fe_sq(tt, p.T);
+        fe_sub(l, yy, xx);
+        fe_mul(r, tt, fe_d());
+        fe_add(r, r, zz);
+        fe_mul(xy, p.X, p.Y);
+        fe_mul(zt, p.Z, p.T);
+        if (!fe_eq(l, r) || !fe_eq(xy, zt) || fe_iszero(p.Z)) return BPG_EFORMAT;
+        ge_add(acc, acc, p);
+    }
+    ristretto_encode(out32, acc);
     return BPG_OK;
 }
 

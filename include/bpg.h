@@ -91,6 +91,17 @@ int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, s
                    bpg_msm_job **job);
 int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32);
 
+/* Point-range sharding (one large MSM split over the GPUs of a node):
+ * each rank runs its range with bpg_msm_submit(), takes its partial sums with
+ * bpg_msm_wait_partial() (n_targets x 128 B: extended coordinates X|Y|Z|T,
+ * 32-byte little-endian each, not normalised), the ranks exchange them
+ * (an all-gather of 128 B per rank over RCCL), and bpg_msm_combine_partials()
+ * adds the k partials and compresses.  Replaces nothing in dalek (its MSM is
+ * single-threaded); the combined result equals the unsharded MSM's encoding.
+ * combine returns BPG_EFORMAT if a partial is not a point of the curve. */
+int bpg_msm_wait_partial(bpg_msm_job *job, uint8_t *out128);
+int bpg_msm_combine_partials(const uint8_t *partials128, size_t k, uint8_t out32[32]);
+
 /* Same, but the scalar row addresses table entries through up to 4 segments:
  * scalar i in segment k (segments concatenated) multiplies table entry
  * seg_start[k] + (i - sum of earlier seg_len).  This is how <a,G[0..n)> +
