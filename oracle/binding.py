@@ -47,6 +47,12 @@ class Oracle:
         self.lib.oracle_msm_ge(out, scalars32, arr, ctypes.c_size_t(n), schedule)
         return out.raw
 
+    def msm_partial(self, scalars32, arr, n, schedule=SCHED_VARTIME):
+        """128-byte un-normalised extended result (the sharding wire format)."""
+        out = ctypes.create_string_buffer(128)
+        self.lib.oracle_msm_ge_ext(out, scalars32, arr, ctypes.c_size_t(n), schedule)
+        return out.raw
+
     def msm_compressed(self, scalars32, points32, schedule=SCHED_VARTIME):
         out = ctypes.create_string_buffer(32)
         rc = self.lib.oracle_msm_compressed(out, scalars32, points32, ctypes.c_size_t(len(points32) // 32), schedule)

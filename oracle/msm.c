@@ -199,6 +199,17 @@ void oracle_msm_ge(uint8_t out32[32], const uint8_t *scalars32, const ge *points
     ristretto_encode(out32, &r);
 }
 
+/* un-normalised extended result X|Y|Z|T (4 x 32 B canonical field encodings): the
+ * partial-sum wire format of point-range sharding (include/bpg.h, bpg_msm_wait_partial) */
+void oracle_msm_ge_ext(uint8_t out128[128], const uint8_t *scalars32, const ge *points, size_t n, int schedule) {
+    ge r;
+    dispatch(&r, scalars32, points, n, schedule);
+    fe_tobytes(out128, &r.X);
+    fe_tobytes(out128 + 32, &r.Y);
+    fe_tobytes(out128 + 64, &r.Z);
+    fe_tobytes(out128 + 96, &r.T);
+}
+
 int oracle_msm_compressed(uint8_t out32[32], const uint8_t *scalars32, const uint8_t *points32, size_t n, int schedule) {
     ge *pts = malloc((n ? n : 1) * sizeof(ge));
     int rc = oracle_decode_many(pts, points32, n);
