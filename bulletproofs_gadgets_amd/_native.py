@@ -25,6 +25,8 @@ class BpgError(RuntimeError):
 
 
 _lib = None
+# bpg_rng_fn: void (*)(void *user, uint8_t *out, size_t n)
+RNG_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
 def lib():
@@ -65,6 +67,52 @@ def lib():
         "bpg_msm_plan": (ctypes.c_int, [vp, sz, sz, ip, ip, ip, ip]),
         "bpg_msm_last_kernel_us": (ctypes.c_int, [vp, fp, fp]),
     }
+    u64p, dp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)
+    ci = ctypes.c_int
+    sigs.update({
+        "bpg_gens_create": (ci, [vp, sz, sz, pvp]),
+        "bpg_gens_free": (None, [vp]),
+        "bpg_gens_capacity": (sz, [vp]),
+        "bpg_gens_export": (ci, [vp, vp, ci, sz, sz, vp]),
+        "bpg_prover_new": (ci, [vp, cp, sz, pvp]),
+        "bpg_prover_free": (None, [vp]),
+        "bpg_prover_cs": (vp, [vp]),
+        "bpg_prover_commit": (ci, [vp, cp, cp, vp, u64p]),
+        "bpg_prover_commit_batch": (ci, [vp, cp, cp, sz, vp, u64p]),
+        "bpg_prover_prove": (ci, [vp, RNG_FN, vp, vp, sz, psz]),
+        "bpg_prover_stats": (ci, [vp, psz, psz]),
+        "bpg_prover_timing": (ci, [vp, dp]),
+        "bpg_verifier_new": (ci, [cp, sz, pvp]),
+        "bpg_verifier_free": (None, [vp]),
+        "bpg_verifier_cs": (vp, [vp]),
+        "bpg_verifier_commit": (ci, [vp, cp, u64p]),
+        "bpg_verifier_verify": (ci, [vp, vp, cp, sz, RNG_FN, vp]),
+        "bpg_verifier_stats": (ci, [vp, psz, psz]),
+        "bpg_cs_multiply": (ci, [vp, u64p, cp, sz, u64p, cp, sz, u64p]),
+        "bpg_cs_allocate_multiplier": (ci, [vp, cp, cp, u64p]),
+        "bpg_cs_constrain": (ci, [vp, u64p, cp, sz]),
+        "bpg_gadget_binary_constrain": (ci, [vp, ctypes.c_uint64]),
+        "bpg_gadget_nonzero": (ci, [vp, u64p, cp, sz, cp]),
+        "bpg_point_from_coords": (ci, [cp, pvp]),
+        "bpg_point_from_vars": (ci, [u64p, pvp]),
+        "bpg_point_free": (None, [vp]),
+        "bpg_edwards_add": (ci, [vp, vp, vp, pvp]),
+        "bpg_edwards_double": (ci, [vp, vp, pvp]),
+        "bpg_edwards_equal": (ci, [vp, vp, vp]),
+        "bpg_edwards_satisfy_curve_eq": (ci, [vp, vp]),
+        "bpg_edwards_conditionally_select": (ci, [vp, vp, u64p, cp, sz, pvp]),
+        "bpg_edwards_scalar_mul": (ci, [vp, vp, u64p, sz, pvp]),
+        "bpg_edwards_prover_commit": (ci, [vp, cp, cp, pvp, vp]),
+        "bpg_edwards_verifier_commit": (ci, [vp, cp, sz, pvp]),
+        "bpg_ristretto_from_point": (ci, [vp, cp, pvp]),
+        "bpg_ristretto_from_lcs": (ci, [vp, vp, sz, pvp]),
+        "bpg_ristretto_add": (ci, [vp, vp, vp, pvp]),
+        "bpg_ristretto_double": (ci, [vp, vp, pvp]),
+        "bpg_ristretto_equals": (ci, [vp, vp, vp]),
+        "bpg_ristretto_conditionally_select": (ci, [vp, vp, u64p, cp, sz, pvp]),
+        "bpg_sk_knowledge_gadget": (ci, [vp, vp, vp, u64p, sz]),
+        "bpg_transcript_kat": (ci, [cp, sz, cp, cp, sz, cp, vp, sz]),
+    })
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)        # AttributeError here == header / library mismatch
         fn.restype = res

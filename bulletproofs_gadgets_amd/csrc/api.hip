@@ -94,6 +94,39 @@ __global__ void __launch_bounds__(256) k_compress(const aniels_rec *__restrict__
     o[1] = make_uint4(b[4], b[5], b[6], b[7]);
 }
 
+// Fill table entries [dst, dst + n) from host bytes (used by the generator table and by
+// the verifier's per-proof points).  uniform: 64 B each (from_uniform_bytes);
+// compressed: 32 B each (decompress); *n_bad receives the number of invalid encodings.
+int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n) {
+    if (!n) return BPG_OK;
+    uint8_t *d_in = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, dst, n);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_in);
+    return BPG_OK;
+}
+
+int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad) {
+    *n_bad = 0;
+    if (!n) return BPG_OK;
+    uint8_t *d_in = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
+    uint32_t *d_flag = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_flag, 4));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, dst, n, d_flag);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipMemcpyAsync(n_bad, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_in);
+    (void)hipFree(d_flag);
+    return BPG_OK;
+}
+
 }  // namespace bpg
 
 using namespace bpg;
@@ -129,6 +162,7 @@ void bpg_shutdown(bpg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto *j : ctx->jobs) msm_job_destroy(j);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

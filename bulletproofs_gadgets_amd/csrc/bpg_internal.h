@@ -98,11 +98,16 @@ struct bpg_ctx {
     std::vector<bpg_msm_job *> jobs;
     bpg::msm_tuning tune;
     float last_acc_us = 0.f, last_total_us = 0.f;
+    // bump arena for the R1CS scalar-vector kernels (grown on demand, reused across proofs)
+    void *ws = nullptr;
+    size_t ws_cap = 0;
 };
 
 namespace bpg {
 int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
                const void *scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job);
+int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n);
+int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);
 int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]);
 void msm_job_destroy(bpg_msm_job *job);

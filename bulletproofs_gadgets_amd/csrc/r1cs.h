@@ -1,0 +1,198 @@
+// r1cs.h -- host side of the product's R1CS layer: Variable / LinearCombination /
+// ConstraintSystem (the interface the reference's gadgets are written against:
+// `cs: &mut dyn ConstraintSystem`, ref: src/gadgets/point/edwards_point.rs:28),
+// Prover, Verifier, generators, the proof object, and zerocaf's Sonny curve for
+// witness values.  Circuit capture is host work (it is the gadget API that "stays
+// as it is"); prove() / verify() drive the HIP kernels (r1cs.hip, msm.hip).
+//
+// Mirrors bulletproofs::r1cs (git develop, feature yoloproofs; ref: Cargo.toml:15-18):
+//   Prover::new/commit/prove      ref: tests/edwards_point.rs:28,31,47
+//   Verifier::new/commit/verify   ref: tests/edwards_point.rs:61,63,79
+//   ConstraintSystem::multiply / allocate_multiplier / constrain
+//                                 ref: edwards_point.rs:45; scalar.rs:10-21; boolean.rs:20
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "bpg_internal.h"
+#include "merlin.h"
+
+namespace bpg {
+
+// ---- scalar convenience (host) ------------------------------------------------
+struct Scalar {
+    sc v;
+    Scalar() : v(sc_zero()) {}
+    Scalar(const sc &x) : v(x) {}
+    Scalar(uint64_t x) : v(sc_from_u64(x)) {}
+    static Scalar from_bytes(const uint8_t b[32]) {      // Scalar::from_bytes_mod_order
+        sc t, r;
+        sc_frombytes(t, b);
+        sc_reduce256(r, t);
+        return Scalar(r);
+    }
+    void to_bytes(uint8_t b[32]) const { sc_tobytes(b, v); }
+    Scalar operator+(const Scalar &o) const { sc r; sc_add(r, v, o.v); return r; }
+    Scalar operator-(const Scalar &o) const { sc r; sc_sub(r, v, o.v); return r; }
+    Scalar operator*(const Scalar &o) const { sc r; sc_mul(r, v, o.v); return r; }
+    Scalar operator-() const { sc r; sc_neg(r, v); return r; }
+    Scalar &operator+=(const Scalar &o) { sc_add(v, v, o.v); return *this; }
+    Scalar &operator-=(const Scalar &o) { sc_sub(v, v, o.v); return *this; }
+    Scalar &operator*=(const Scalar &o) { sc_mul(v, v, o.v); return *this; }
+    bool operator==(const Scalar &o) const { return sc_eq(v, o.v); }
+    bool is_zero() const { return sc_is_zero(v); }
+    Scalar invert() const { sc r; sc_invert(r, v); return r; }
+};
+
+// ---- variables and linear combinations ---------------------------------------
+enum VarKind : uint32_t { VAR_COMMITTED = 0, VAR_LEFT = 1, VAR_RIGHT = 2, VAR_OUTPUT = 3, VAR_ONE = 4 };
+struct Variable {
+    uint32_t kind, index;
+    static Variable One() { return Variable{VAR_ONE, 0}; }
+};
+
+struct Term {
+    Variable var;
+    Scalar coeff;
+};
+
+struct LinearCombination {
+    std::vector<Term> terms;
+    LinearCombination() {}
+    LinearCombination(const Variable &v) { terms.push_back({v, Scalar(1)}); }
+    LinearCombination(const Scalar &s) { terms.push_back({Variable::One(), s}); }
+    LinearCombination &operator+=(const LinearCombination &o) {
+        terms.insert(terms.end(), o.terms.begin(), o.terms.end());
+        return *this;
+    }
+    LinearCombination &operator-=(const LinearCombination &o) {
+        for (const auto &t : o.terms) terms.push_back({t.var, -t.coeff});
+        return *this;
+    }
+    LinearCombination operator+(const LinearCombination &o) const { LinearCombination r = *this; r += o; return r; }
+    LinearCombination operator-(const LinearCombination &o) const { LinearCombination r = *this; r -= o; return r; }
+    LinearCombination operator-() const { LinearCombination r; r -= *this; return r; }
+};
+using LC = LinearCombination;
+
+struct R1CSError : std::runtime_error {
+    int code;
+    R1CSError(int c, const char *what) : std::runtime_error(what), code(c) {}
+};
+
+// ---- constraint system --------------------------------------------------------
+// Constraints are stored flat (structure of arrays) so prove()/verify() can hand
+// them to the GPU flattening kernel without re-walking LC objects:
+//   term t: variable (kind, index), coefficient id (dictionary: circuits use a
+//   handful of distinct coefficients), constraint q = number of constrain() calls before it.
+struct ConstraintStore {
+    std::vector<uint32_t> term_var;      // kind << 28 | index   (index < 2^28)
+    std::vector<uint32_t> term_coeff;    // index into coeffs
+    std::vector<uint32_t> term_q;        // constraint number
+    std::vector<sc> coeffs;
+    std::unordered_map<uint64_t, std::vector<uint32_t>> coeff_lookup;   // hash -> ids
+    uint32_t num_constraints = 0;
+    uint32_t intern(const sc &c);
+    void push(const LinearCombination &lc);
+};
+
+class ConstraintSystem {
+  public:
+    virtual ~ConstraintSystem() {}
+    struct Triple { Variable l, r, o; };
+    virtual Triple multiply(LinearCombination left, LinearCombination right) = 0;
+    // assignment may be null (verifier side / missing witness)
+    virtual Triple allocate_multiplier(const Scalar *left, const Scalar *right) = 0;
+    virtual void constrain(const LinearCombination &lc) = 0;
+    virtual bool is_prover() const = 0;
+};
+
+// ---- generators ----------------------------------------------------------------
+// PedersenGens::default() and BulletproofGens::new(cap, 1), resident on one GPU:
+// table = [ G_0..G_{cap-1} | H_0..H_{cap-1} | B | B_blinding | scratch for proof points ].
+struct Gens {
+    bpg_ctx *ctx = nullptr;
+    bpg_points *table = nullptr;
+    size_t capacity = 0, dyn_capacity = 0;
+    size_t off_G() const { return 0; }
+    size_t off_H() const { return capacity; }
+    size_t off_B() const { return 2 * capacity; }
+    size_t off_Bb() const { return 2 * capacity + 1; }
+    size_t off_dyn() const { return 2 * capacity + 2; }
+};
+int gens_create(bpg_ctx *ctx, size_t capacity, size_t dyn_capacity, Gens **out);
+void gens_destroy(Gens *g);
+
+// ---- proof ----------------------------------------------------------------------
+struct R1CSProof {
+    uint8_t A_I1[32], A_O1[32], S1[32], A_I2[32], A_O2[32], S2[32], T_1[32], T_3[32], T_4[32], T_5[32], T_6[32];
+    Scalar t_x, t_x_blinding, e_blinding;
+    std::vector<uint8_t> L_vec, R_vec;     // lg n x 32 B each
+    Scalar a, b;
+    std::vector<uint8_t> to_bytes() const;
+    static bool from_bytes(const uint8_t *data, size_t len, R1CSProof &out);
+};
+
+// external randomness (the reference passes &mut thread_rng(), ref: tests/edwards_point.rs:79)
+typedef void (*rng_fill_fn)(void *user, uint8_t *out, size_t n);
+
+class Prover : public ConstraintSystem {
+  public:
+    Prover(Gens *gens, const void *label, size_t label_len);
+    // Prover::commit; V32 receives the compressed commitment
+    Variable commit(const Scalar &v, const Scalar &v_blinding, uint8_t V32[32]);
+    // batch form: one GPU launch for m commitments, transcript order preserved
+    void commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, uint8_t *V32, Variable *vars);
+    Triple multiply(LinearCombination left, LinearCombination right) override;
+    Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
+    void constrain(const LinearCombination &lc) override { cs_.push(lc); }
+    bool is_prover() const override { return true; }
+    Scalar eval(const LinearCombination &lc) const;
+    // Prover::prove(bp_gens); returns BPG_OK or a negative BPG_E* code
+    int prove(rng_fill_fn rng, void *rng_user, R1CSProof &out);
+    size_t num_multipliers() const { return a_L_.size(); }
+    size_t num_constraints() const { return cs_.num_constraints; }
+    Transcript &transcript() { return tr_; }
+    struct Timing { double rng_ms = 0, commit_ms = 0, poly_ms = 0, ipp_ms = 0, total_ms = 0; } timing;
+
+  private:
+    Gens *gens_;
+    Transcript tr_;
+    ConstraintStore cs_;
+    std::vector<sc> a_L_, a_R_, a_O_, v_, v_blinding_;
+};
+
+class Verifier : public ConstraintSystem {
+  public:
+    Verifier(const void *label, size_t label_len);
+    Variable commit(const uint8_t V32[32]);
+    Triple multiply(LinearCombination left, LinearCombination right) override;
+    Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
+    void constrain(const LinearCombination &lc) override { cs_.push(lc); }
+    bool is_prover() const override { return false; }
+    // Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng); BPG_OK or BPG_EVERIFY / BPG_EGENS / ...
+    int verify(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user);
+    size_t num_multipliers() const { return num_vars_; }
+    size_t num_constraints() const { return cs_.num_constraints; }
+
+  private:
+    Transcript tr_;
+    ConstraintStore cs_;
+    size_t num_vars_ = 0;
+    std::vector<uint8_t> V_;
+};
+
+// ---- zerocaf "Sonny" curve over F_l (witness values only) -------------------------
+struct SonnyPoint {
+    Scalar X, Y, Z, T;
+    static SonnyPoint identity() { return {Scalar(0), Scalar(1), Scalar(1), Scalar(0)}; }
+};
+Scalar sonny_a();     // zerocaf::constants::EDWARDS_A  (= -1)
+Scalar sonny_d();     // zerocaf::constants::EDWARDS_D  (= -86650/86649)
+SonnyPoint sonny_add(const SonnyPoint &p, const SonnyPoint &q);   // add-2008-hwcd, the formula the gadgets arithmetise
+inline SonnyPoint sonny_double(const SonnyPoint &p) { return sonny_add(p, p); }
+
+}  // namespace bpg

@@ -1,0 +1,1015 @@
+// r1cs.hip -- Prover::prove / Verifier::verify / Prover::commit of bulletproofs::r1cs
+// on MI355X (ref call sites: tests/edwards_point.rs:31,47,79; see r1cs.h), plus the
+// scalar-vector kernels mod l (constraint flattening, l(x)/r(x)/t(x), inner-product
+// folding) and the fixed-base Pedersen kernel.
+//
+// Design:
+//  * Every group operation of the proof is a fixed-base MSM over the resident generator
+//    table [G | H | B | B~] (msm.hip).  The inner-product argument never folds points:
+//    the folded generators of round k are G'_i = sum_{j = i mod n_k} sG_j G_j with
+//    sG_j = G_factor_j * prod_{t<k} u_t^{+-1}, so L_k and R_k are MSMs over the ORIGINAL
+//    table with scalars a'_{.}*sG_j (and b'_{.}*sH_j): group results are exact, so the
+//    bytes equal what per-round folding (dalek) produces, with no 253-doubling chain per
+//    round on the GPU's slow single-lane path.
+//  * Scalars mod l live in HBM as 32-byte little-endian values; one thread per element.
+//  * The transcript (one Keccak chain) and the blinding RNG stay on the host.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "r1cs.h"
+
+namespace bpg {
+
+// =================================================================== device helpers
+
+__device__ __forceinline__ sc ld_sc(const sc *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1];
+    sc r = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+    return r;
+}
+__device__ __forceinline__ void st_sc(sc *p, const sc &v) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    q[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+}
+__device__ __forceinline__ sc mul_(const sc &a, const sc &b) { sc r; sc_mul(r, a, b); return r; }
+__device__ __forceinline__ sc add_(const sc &a, const sc &b) { sc r; sc_add(r, a, b); return r; }
+__device__ __forceinline__ sc sub_(const sc &a, const sc &b) { sc r; sc_sub(r, a, b); return r; }
+
+// x^e from a table of x^(2^k), k < 32
+__device__ __forceinline__ sc pow_tbl(const sc *tbl, uint32_t e) {
+    sc acc = sc_one();
+    for (int k = 0; e; k++, e >>= 1)
+        if (e & 1) acc = mul_(acc, ld_sc(tbl + k));
+    return acc;
+}
+
+// block-wide sum of NS scalars per thread (256 threads); thread 0 writes out[block*NS + s]
+template <int NS>
+__device__ void block_sum(sc (&v)[NS], sc *out) {
+    __shared__ uint32_t sm[NS][8][256];
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) sm[s][k][t] = v[s].v[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if (t < stride) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                sc a, b;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    a.v[k] = sm[s][k][t];
+                    b.v[k] = sm[s][k][t + stride];
+                }
+                sc_add(a, a, b);
+#pragma unroll
+                for (int k = 0; k < 8; k++) sm[s][k][t] = a.v[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            sc a;
+#pragma unroll
+            for (int k = 0; k < 8; k++) a.v[k] = sm[s][k][0];
+            st_sc(out + (size_t)blockIdx.x * NS + s, a);
+        }
+    }
+}
+
+// =================================================================== kernels
+
+// zpow[q] = z^(q+1)
+__global__ void __launch_bounds__(256) k_zpow(const sc *__restrict__ ztbl, sc *__restrict__ zpow, uint32_t Q) {
+    uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q < Q) st_sc(zpow + q, pow_tbl(ztbl, q + 1));
+}
+
+// Flattened constraints: W[slot] = (+/-) sum over the slot's terms of z^(q+1) * coeff.
+// Slots: [0,n) wL, [n,2n) wR, [2n,3n) wO, [3n,3n+m) wV (negated), 3n+m: wc (negated).
+__global__ void __launch_bounds__(256) k_flatten(const uint32_t *__restrict__ slot_off, const uint32_t *__restrict__ t_coeff,
+                                                 const uint32_t *__restrict__ t_q, const sc *__restrict__ coeffs,
+                                                 const sc *__restrict__ zpow, sc *__restrict__ W, uint32_t nslots,
+                                                 uint32_t neg_from) {
+    uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nslots) return;
+    sc acc = sc_zero();
+    for (uint32_t t = slot_off[s]; t < slot_off[s + 1]; t++) acc = add_(acc, mul_(ld_sc(zpow + t_q[t]), ld_sc(coeffs + t_coeff[t])));
+    if (s >= neg_from) sc_neg(acc, acc);
+    st_sc(W + s, acc);
+}
+
+// l(X), r(X) coefficient vectors and the per-block partial sums of t1..t6
+//   l1 = a_L + y^-i wR   l2 = a_O   l3 = s_L      r0 = wO - y^i   r1 = y^i a_R + wL   r3 = y^i s_R
+__global__ void __launch_bounds__(256) k_poly(uint32_t n, const sc *__restrict__ aL, const sc *__restrict__ aR,
+                                              const sc *__restrict__ aO, const sc *__restrict__ sL, const sc *__restrict__ sR,
+                                              const sc *__restrict__ W, const sc *__restrict__ ytbl,
+                                              const sc *__restrict__ yinvtbl, sc *__restrict__ l1, sc *__restrict__ r0,
+                                              sc *__restrict__ r1, sc *__restrict__ r3, sc *__restrict__ partial) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    sc t[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) t[k] = sc_zero();
+    if (i < n) {
+        sc yi = pow_tbl(ytbl, i), yinvi = pow_tbl(yinvtbl, i);
+        sc wL = ld_sc(W + i), wR = ld_sc(W + n + i), wO = ld_sc(W + 2 * (size_t)n + i);
+        sc vl1 = add_(ld_sc(aL + i), mul_(yinvi, wR));
+        sc vl2 = ld_sc(aO + i), vl3 = ld_sc(sL + i);
+        sc vr0 = sub_(wO, yi);
+        sc vr1 = add_(mul_(yi, ld_sc(aR + i)), wL);
+        sc vr3 = mul_(yi, ld_sc(sR + i));
+        st_sc(l1 + i, vl1);
+        st_sc(r0 + i, vr0);
+        st_sc(r1 + i, vr1);
+        st_sc(r3 + i, vr3);
+        t[0] = mul_(vl1, vr0);
+        t[1] = add_(mul_(vl1, vr1), mul_(vl2, vr0));
+        t[2] = add_(mul_(vl2, vr1), mul_(vl3, vr0));
+        t[3] = add_(mul_(vl1, vr3), mul_(vl3, vr1));
+        t[4] = mul_(vl2, vr3);
+        t[5] = mul_(vl3, vr3);
+    }
+    block_sum<6>(t, partial);
+}
+
+// l(x), r(x) -> the IPP's a, b (length np, padded), and the generator factor vectors
+//   sG_j = G_factors[j] = 1 (j < n) | u (pad)      sH_j = y^-j * G_factors[j]
+__global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, sc x, sc u, const sc *__restrict__ l1,
+                                              const sc *__restrict__ aO, const sc *__restrict__ sL, const sc *__restrict__ r0,
+                                              const sc *__restrict__ r1, const sc *__restrict__ r3,
+                                              const sc *__restrict__ ytbl, const sc *__restrict__ yinvtbl, sc *__restrict__ a,
+                                              sc *__restrict__ b, sc *__restrict__ sG, sc *__restrict__ sH) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= np) return;
+    sc yinvi = pow_tbl(yinvtbl, i);
+    if (i < n) {
+        // l = x (l1 + x (l2 + x l3));  r = r0 + x (r1 + x (x r3))
+        sc l = mul_(x, add_(ld_sc(l1 + i), mul_(x, add_(ld_sc(aO + i), mul_(x, ld_sc(sL + i))))));
+        sc r = add_(ld_sc(r0 + i), mul_(x, add_(ld_sc(r1 + i), mul_(x, mul_(x, ld_sc(r3 + i))))));
+        st_sc(a + i, l);
+        st_sc(b + i, r);
+        st_sc(sG + i, sc_one());
+        st_sc(sH + i, yinvi);
+    } else {
+        sc yi = pow_tbl(ytbl, i), neg;
+        sc_neg(neg, yi);
+        st_sc(a + i, sc_zero());
+        st_sc(b + i, neg);
+        st_sc(sG + i, u);
+        st_sc(sH + i, mul_(yinvi, u));
+    }
+}
+
+// One IPP round, scalar side.  n_k = current vector length, half = n_k / 2.
+// rows: rowL / rowR have 2*np + 1 scalars: [ G_0..G_{np-1} | H_0..H_{np-1} | B ].
+//   G_j (idx = j mod n_k): idx >= half -> L gets a[idx-half] * sG_j, else R gets a[idx+half] * sG_j
+//   H_j:                   idx <  half -> L gets b[idx+half] * sH_j, else R gets b[idx-half] * sH_j
+// partial[block] = per-block sums of (c_L, c_R) terms, c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo>.
+__global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, const sc *__restrict__ a, const sc *__restrict__ b,
+                                                  const sc *__restrict__ sG, const sc *__restrict__ sH, sc *__restrict__ rowL,
+                                                  sc *__restrict__ rowR, sc *__restrict__ partial) {
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    sc c[2] = {sc_zero(), sc_zero()};
+    if (j < np) {
+        const uint32_t half = nk >> 1, idx = j & (nk - 1);
+        const bool hi = idx >= half;
+        const uint32_t other = hi ? idx - half : idx + half;
+        sc ga = mul_(ld_sc(a + other), ld_sc(sG + j));
+        sc hb = mul_(ld_sc(b + other), ld_sc(sH + j));
+        const sc zero = sc_zero();
+        st_sc(rowL + j, hi ? ga : zero);
+        st_sc(rowR + j, hi ? zero : ga);
+        st_sc(rowL + np + j, hi ? zero : hb);
+        st_sc(rowR + np + j, hi ? hb : zero);
+        if (j < half) {
+            c[0] = mul_(ld_sc(a + j), ld_sc(b + half + j));
+            c[1] = mul_(ld_sc(a + half + j), ld_sc(b + j));
+        }
+    }
+    block_sum<2>(c, partial);
+}
+
+// finish c_L, c_R and write the B-scalars  c_L * w,  c_R * w  (Q = w B)
+__global__ void __launch_bounds__(256) k_ipp_c(const sc *__restrict__ partial, uint32_t nblocks, sc w, sc *__restrict__ outL,
+                                               sc *__restrict__ outR) {
+    __shared__ sc res[2];
+    sc c[2] = {sc_zero(), sc_zero()};
+    for (uint32_t k = threadIdx.x; k < nblocks; k += 256) {
+        c[0] = add_(c[0], ld_sc(partial + 2 * (size_t)k));
+        c[1] = add_(c[1], ld_sc(partial + 2 * (size_t)k + 1));
+    }
+    block_sum<2>(c, res);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st_sc(outL, mul_(res[0], w));
+        st_sc(outR, mul_(res[1], w));
+    }
+}
+
+// fold: a' = u a_lo + u^-1 a_hi, b' = u^-1 b_lo + u b_hi; sG_j *= (hi ? u : u^-1), sH_j *= (hi ? u^-1 : u)
+__global__ void __launch_bounds__(256) k_ipp_fold(uint32_t np, uint32_t nk, sc u, sc uinv, sc *__restrict__ a, sc *__restrict__ b,
+                                                  sc *__restrict__ sG, sc *__restrict__ sH) {
+    uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= np) return;
+    const uint32_t half = nk >> 1, idx = j & (nk - 1);
+    const bool hi = idx >= half;
+    st_sc(sG + j, mul_(ld_sc(sG + j), hi ? u : uinv));
+    st_sc(sH + j, mul_(ld_sc(sH + j), hi ? uinv : u));
+    if (j < half) {
+        sc na = add_(mul_(ld_sc(a + j), u), mul_(uinv, ld_sc(a + half + j)));
+        sc nb = add_(mul_(ld_sc(b + j), uinv), mul_(u, ld_sc(b + half + j)));
+        st_sc(a + j, na);
+        st_sc(b + j, nb);
+    }
+}
+
+// Verifier: g / h scalars of the combined check, and the per-block sums of delta = <y^-i wR_i, wL_i>
+//   s_i = prod_k (bit_{lg-1-k}(i) ? u_k : u_k^-1)
+//   g_i = ufor_i (x y^-i wR_i - a s_i)      h_i = ufor_i (y^-i (x wL_i + wO_i - b s_{np-1-i}) - 1)
+struct verify_args {
+    sc x, a, b, u;
+    uint32_t n, np, lg;
+};
+__global__ void __launch_bounds__(256) k_verify_scalars(verify_args A, const sc *__restrict__ W, const sc *__restrict__ yinvtbl,
+                                                        const sc *__restrict__ uk, const sc *__restrict__ ukinv,
+                                                        sc *__restrict__ g, sc *__restrict__ h, sc *__restrict__ partial) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    sc d[1] = {sc_zero()};
+    if (i < A.np) {
+        sc s = sc_one(), srev = sc_one();
+        const uint32_t irev = A.np - 1 - i;
+        for (uint32_t k = 0; k < A.lg; k++) {
+            const uint32_t bit = A.lg - 1 - k;
+            sc f = ld_sc(uk + k), fi = ld_sc(ukinv + k);
+            s = mul_(s, ((i >> bit) & 1) ? f : fi);
+            srev = mul_(srev, ((irev >> bit) & 1) ? f : fi);
+        }
+        sc yinvi = pow_tbl(yinvtbl, i);
+        sc wL = sc_zero(), wR = sc_zero(), wO = sc_zero();
+        if (i < A.n) {
+            wL = ld_sc(W + i);
+            wR = ld_sc(W + A.n + i);
+            wO = ld_sc(W + 2 * (size_t)A.n + i);
+        }
+        sc yneg_wR = mul_(wR, yinvi);
+        d[0] = mul_(yneg_wR, wL);
+        sc gi = sub_(mul_(A.x, yneg_wR), mul_(A.a, s));
+        sc hi = sub_(mul_(yinvi, sub_(add_(mul_(A.x, wL), wO), mul_(A.b, srev))), sc_one());
+        if (i >= A.n) {
+            gi = mul_(gi, A.u);
+            hi = mul_(hi, A.u);
+        }
+        st_sc(g + i, gi);
+        st_sc(h + i, hi);
+    }
+    block_sum<1>(d, partial);
+}
+
+// K3: fixed-base Pedersen commitments v B + r B~ with radix-16 comb tables, compressed on the device.
+// comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels)
+__global__ void __launch_bounds__(64) k_pedersen(const aniels_rec *__restrict__ comb, const sc *__restrict__ scalars /* [m][2] */,
+                                                 uint32_t m, uint8_t *__restrict__ out32) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= m) return;
+    ge acc;
+    ge_identity(acc);
+    for (int base = 0; base < 2; base++) {
+        sc s = ld_sc(scalars + 2 * (size_t)i + base);
+        uint32_t carry = 0;
+        for (int w = 0; w < 64; w++) {
+            uint32_t raw = ((s.v[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
+            carry = raw > 8 ? 1u : 0u;
+            int d = (int)raw - (int)(carry << 4);
+            if (d != 0) {
+                int k = d < 0 ? -d : d;
+                const uint32_t *rec = comb[(size_t)(base * 64 + w) * 8 + (k - 1)].w;
+                ge_aniels q;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    q.YpX.v[t] = rec[t];
+                    q.YmX.v[t] = rec[8 + t];
+                    q.T2d.v[t] = rec[16 + t];
+                }
+                ge_madd(acc, acc, q, d < 0);
+            }
+        }
+        // scalars are < 2^253, so the final carry is always 0
+    }
+    uint32_t enc[8];
+    ristretto_encode_w(enc, acc);
+    uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * (size_t)i);
+    o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+    o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+}
+
+// comb table construction: thread (base, w, k) computes k * 16^w * base by double-and-add
+__global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict__ bases /* B, B~ */, aniels_rec *__restrict__ comb) {
+    uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= 2 * 64 * 8) return;
+    const int base = i / 512, w = (i / 8) % 64, k = (i % 8) + 1;
+    const uint32_t *rec = bases[base].w;
+    ge_aniels q;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        q.YpX.v[t] = rec[t];
+        q.YmX.v[t] = rec[8 + t];
+        q.T2d.v[t] = rec[16 + t];
+    }
+    ge acc;
+    ge_identity(acc);
+    for (int r = 0; r < k; r++) ge_madd(acc, acc, q, false);      // k * base
+    for (int r = 0; r < 4 * w; r++) ge_double(acc, acc);          // * 16^w
+    fe zinv;
+    fe_invert(zinv, acc.Z);
+    ge_aniels o;
+    ge_to_aniels(o, acc, zinv);
+    uint32_t *dst = comb[i].w;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        dst[t] = o.YpX.v[t];
+        dst[8 + t] = o.YmX.v[t];
+        dst[16 + t] = o.T2d.v[t];
+        dst[24 + t] = 0;
+    }
+}
+
+// =================================================================== host: store / sonny / proof bytes
+
+uint32_t ConstraintStore::intern(const sc &c) {
+    uint64_t h = ((uint64_t)c.v[1] << 32 | c.v[0]) ^ ((uint64_t)c.v[7] << 32 | c.v[4]) * 0x9e3779b97f4a7c15ULL;
+    auto &ids = coeff_lookup[h];
+    for (uint32_t id : ids)
+        if (sc_eq(coeffs[id], c)) return id;
+    coeffs.push_back(c);
+    ids.push_back((uint32_t)coeffs.size() - 1);
+    return (uint32_t)coeffs.size() - 1;
+}
+
+void ConstraintStore::push(const LinearCombination &lc) {
+    for (const auto &t : lc.terms) {
+        term_var.push_back(t.var.kind << 28 | t.var.index);
+        term_coeff.push_back(intern(t.coeff.v));
+        term_q.push_back(num_constraints);
+    }
+    num_constraints++;
+}
+
+Scalar sonny_a() { return -Scalar(1); }
+Scalar sonny_d() {
+    static const Scalar d = -(Scalar(86650) * Scalar(86649).invert());
+    return d;
+}
+SonnyPoint sonny_add(const SonnyPoint &p, const SonnyPoint &q) {
+    Scalar A = p.X * q.X, B = p.Y * q.Y, C = sonny_d() * p.T * q.T, D = p.Z * q.Z;
+    Scalar E = (p.X + p.Y) * (q.X + q.Y) - A - B, F = D - C, G = D + C, H = B + A;
+    return {E * F, G * H, F * G, E * H};
+}
+
+std::vector<uint8_t> R1CSProof::to_bytes() const {
+    static const uint8_t zero[32] = {0};
+    bool one_phase = !memcmp(A_I2, zero, 32) && !memcmp(A_O2, zero, 32) && !memcmp(S2, zero, 32);
+    std::vector<uint8_t> out;
+    auto put = [&](const uint8_t *p) { out.insert(out.end(), p, p + 32); };
+    auto puts = [&](const Scalar &s) {
+        uint8_t b[32];
+        s.to_bytes(b);
+        put(b);
+    };
+    out.push_back(one_phase ? 0 : 1);
+    put(A_I1); put(A_O1); put(S1);
+    if (!one_phase) { put(A_I2); put(A_O2); put(S2); }
+    put(T_1); put(T_3); put(T_4); put(T_5); put(T_6);
+    puts(t_x); puts(t_x_blinding); puts(e_blinding);
+    for (size_t k = 0; k < L_vec.size() / 32; k++) {
+        put(&L_vec[32 * k]);
+        put(&R_vec[32 * k]);
+    }
+    puts(a); puts(b);
+    return out;
+}
+
+bool R1CSProof::from_bytes(const uint8_t *d, size_t len, R1CSProof &o) {
+    if (len < 1 || d[0] > 1) return false;
+    const size_t k = d[0] == 0 ? 11 : 14;
+    const uint8_t *p = d + 1;
+    size_t body = len - 1;
+    if (body % 32 || body / 32 < k + 2 || ((body / 32 - k - 2) & 1)) return false;
+    size_t nch = body / 32, i = 0;
+    auto take = [&](uint8_t *dst) { memcpy(dst, p + 32 * i++, 32); };
+    auto takes = [&](Scalar &s) {
+        sc t;
+        sc_frombytes(t, p + 32 * i++);
+        if (!sc_is_canonical(t)) return false;
+        s = Scalar(t);
+        return true;
+    };
+    take(o.A_I1); take(o.A_O1); take(o.S1);
+    if (k == 14) { take(o.A_I2); take(o.A_O2); take(o.S2); }
+    else { memset(o.A_I2, 0, 32); memset(o.A_O2, 0, 32); memset(o.S2, 0, 32); }
+    take(o.T_1); take(o.T_3); take(o.T_4); take(o.T_5); take(o.T_6);
+    if (!takes(o.t_x) || !takes(o.t_x_blinding) || !takes(o.e_blinding)) return false;
+    size_t lg = (nch - i - 2) / 2;
+    if (lg >= 32) return false;
+    o.L_vec.resize(32 * lg);
+    o.R_vec.resize(32 * lg);
+    for (size_t r = 0; r < lg; r++) {
+        memcpy(&o.L_vec[32 * r], p + 32 * i++, 32);
+        memcpy(&o.R_vec[32 * r], p + 32 * i++, 32);
+    }
+    return takes(o.a) && takes(o.b);
+}
+
+// =================================================================== host: device arena + helpers
+
+struct Arena {
+    bpg_ctx *ctx;
+    size_t used = 0;
+    explicit Arena(bpg_ctx *c) : ctx(c) {}
+    int reserve(size_t bytes) {
+        if (bytes <= ctx->ws_cap) return BPG_OK;
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_cap = 0;
+        size_t want = bytes + bytes / 4 + (1 << 20);
+        BPG_CHECK_HIP(hipMalloc(&ctx->ws, want));
+        ctx->ws_cap = want;
+        return BPG_OK;
+    }
+    template <typename T>
+    T *take(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        T *p = (T *)((uint8_t *)ctx->ws + used);
+        used += bytes;
+        return p;
+    }
+};
+static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static void pow2_table(sc out[32], const sc &x) {
+    out[0] = x;
+    for (int k = 1; k < 32; k++) sc_mul(out[k], out[k - 1], out[k - 1]);
+}
+
+static unsigned grid256(size_t n) { return (unsigned)((n + 255) / 256); }
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// slots by variable: counting sort of the constraint terms (host, O(terms))
+struct FlatPlan {
+    std::vector<uint32_t> slot_off, t_coeff, t_q;
+    uint32_t nslots = 0, neg_from = 0;
+};
+static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc, FlatPlan &fp) {
+    fp.nslots = 3 * n + m + (want_wc ? 1 : 0);
+    fp.neg_from = 3 * n;
+    fp.slot_off.assign(fp.nslots + 1, 0);
+    const size_t nt = cs.term_var.size();
+    auto slot_of = [&](uint32_t tv) -> int64_t {
+        uint32_t kind = tv >> 28, idx = tv & 0x0fffffffu;
+        switch (kind) {
+            case VAR_LEFT: return idx;
+            case VAR_RIGHT: return (int64_t)n + idx;
+            case VAR_OUTPUT: return 2 * (int64_t)n + idx;
+            case VAR_COMMITTED: return 3 * (int64_t)n + idx;
+            default: return want_wc ? 3 * (int64_t)n + m : -1;
+        }
+    };
+    for (size_t t = 0; t < nt; t++) {
+        int64_t s = slot_of(cs.term_var[t]);
+        if (s >= 0) fp.slot_off[s + 1]++;
+    }
+    for (uint32_t s = 0; s < fp.nslots; s++) fp.slot_off[s + 1] += fp.slot_off[s];
+    std::vector<uint32_t> cur(fp.slot_off.begin(), fp.slot_off.end() - 1);
+    fp.t_coeff.resize(fp.slot_off[fp.nslots]);
+    fp.t_q.resize(fp.slot_off[fp.nslots]);
+    for (size_t t = 0; t < nt; t++) {
+        int64_t s = slot_of(cs.term_var[t]);
+        if (s < 0) continue;
+        uint32_t pos = cur[s]++;
+        fp.t_coeff[pos] = cs.term_coeff[t];
+        fp.t_q[pos] = cs.term_q[t];
+    }
+}
+
+// runs k_zpow + k_flatten; W (device) receives nslots scalars
+static int gpu_flatten(bpg_ctx *ctx, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W) {
+    hipStream_t s = ctx->stream;
+    const uint32_t Q = cs.num_constraints;
+    sc ztbl[32];
+    pow2_table(ztbl, z);
+    sc *d_ztbl = ar.take<sc>(32), *d_zpow = ar.take<sc>(Q ? Q : 1), *d_coeffs = ar.take<sc>(cs.coeffs.size() ? cs.coeffs.size() : 1);
+    uint32_t *d_off = ar.take<uint32_t>(fp.nslots + 1), *d_tc = ar.take<uint32_t>(fp.t_coeff.size() + 1),
+             *d_tq = ar.take<uint32_t>(fp.t_q.size() + 1);
+    BPG_CHECK_HIP(hipMemcpyAsync(d_ztbl, ztbl, sizeof ztbl, hipMemcpyHostToDevice, s));
+    if (!cs.coeffs.empty())
+        BPG_CHECK_HIP(hipMemcpyAsync(d_coeffs, cs.coeffs.data(), cs.coeffs.size() * sizeof(sc), hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_off, fp.slot_off.data(), (fp.nslots + 1) * 4, hipMemcpyHostToDevice, s));
+    if (!fp.t_coeff.empty()) {
+        BPG_CHECK_HIP(hipMemcpyAsync(d_tc, fp.t_coeff.data(), fp.t_coeff.size() * 4, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_tq, fp.t_q.data(), fp.t_q.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    if (Q) hipLaunchKernelGGL(k_zpow, dim3(grid256(Q)), dim3(256), 0, s, d_ztbl, d_zpow, Q);
+    if (fp.nslots)
+        hipLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, d_off, d_tc, d_tq, d_coeffs, d_zpow, d_W,
+                           fp.nslots, fp.neg_from);
+    BPG_CHECK_HIP(hipGetLastError());
+    return BPG_OK;
+}
+
+static size_t flatten_bytes(const ConstraintStore &cs, const FlatPlan &fp) {
+    return pad256(32 * 32) + pad256((cs.num_constraints + 1) * 32) + pad256((cs.coeffs.size() + 1) * 32) +
+           pad256((fp.nslots + 1) * 4) + 2 * pad256((fp.t_coeff.size() + 1) * 4);
+}
+
+// =================================================================== generators
+
+struct GensExtra {
+    aniels_rec *d_comb = nullptr;     // 2 x 64 x 8 comb table for B, B~
+};
+static std::unordered_map<Gens *, GensExtra> g_extra;
+
+int gens_create(bpg_ctx *ctx, size_t capacity, size_t dyn_capacity, Gens **out) {
+    if (!ctx || !out || capacity == 0 || capacity > ((size_t)1 << 26)) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    Gens *g = new Gens();
+    g->ctx = ctx;
+    g->capacity = capacity;
+    g->dyn_capacity = dyn_capacity;
+    bpg_points *tbl = new bpg_points();
+    tbl->ctx = ctx;
+    tbl->n = 2 * capacity + 2 + dyn_capacity;
+    tbl->d_table = nullptr;
+    hipError_t e = hipMalloc((void **)&tbl->d_table, tbl->n * sizeof(aniels_rec));
+    if (e != hipSuccess) {
+        set_last_error("hipMalloc(generator table)", e);
+        delete tbl;
+        delete g;
+        return BPG_ENOMEM;
+    }
+    g->table = tbl;
+    // BulletproofGens::new(capacity, 1): GeneratorsChain = SHAKE256("GeneratorsChain" | label), label = 'G'/'H' | u32le(0)
+    std::vector<uint8_t> stream(64 * capacity);
+    int rc;
+    for (int which = 0; which < 2; which++) {
+        KeccakSponge x = shake256();
+        const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
+        x.absorb("GeneratorsChain", 15);
+        x.absorb(label, 5);
+        x.squeeze(stream.data(), stream.size());
+        if ((rc = table_write_uniform(ctx, tbl->d_table + (which ? g->off_H() : g->off_G()), stream.data(), capacity))) return rc;
+    }
+    // PedersenGens::default(): B = ristretto basepoint, B_blinding = from_uniform_bytes(SHA3-512(compress(B)))
+    ge Bp;
+    ge_basepoint(Bp);
+    uint8_t Benc[32], h[64];
+    ristretto_encode(Benc, Bp);
+    uint32_t bad = 0;
+    if ((rc = table_write_compressed(ctx, tbl->d_table + g->off_B(), Benc, 1, &bad)) || bad) return rc ? rc : BPG_EDEVICE;
+    KeccakSponge s3 = sha3_512();
+    s3.absorb(Benc, 32);
+    s3.squeeze(h, 64);
+    if ((rc = table_write_uniform(ctx, tbl->d_table + g->off_Bb(), h, 1))) return rc;
+    GensExtra ex;
+    BPG_CHECK_HIP(hipMalloc((void **)&ex.d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
+    hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, ctx->stream, tbl->d_table + g->off_B(), ex.d_comb);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    g_extra[g] = ex;
+    *out = g;
+    return BPG_OK;
+}
+
+void gens_destroy(Gens *g) {
+    if (!g) return;
+    auto it = g_extra.find(g);
+    if (it != g_extra.end()) {
+        (void)hipFree(it->second.d_comb);
+        g_extra.erase(it);
+    }
+    if (g->table) {
+        (void)hipFree(g->table->d_table);
+        delete g->table;
+    }
+    delete g;
+}
+
+// m Pedersen commitments (K3); scalars = [m][2] host; out32 host
+static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
+    if (!m) return BPG_OK;
+    bpg_ctx *ctx = g->ctx;
+    hipStream_t s = ctx->stream;
+    sc *d_s = nullptr;
+    uint8_t *d_o = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_s, m * 64));
+    BPG_CHECK_HIP(hipMalloc((void **)&d_o, m * 32));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, g_extra[g].d_comb, d_s, (uint32_t)m, d_o);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_s);
+    (void)hipFree(d_o);
+    return BPG_OK;
+}
+
+// =================================================================== Prover
+
+Prover::Prover(Gens *gens, const void *label, size_t label_len) : gens_(gens), tr_(label, label_len) { tr_.r1cs_domain_sep(); }
+
+Variable Prover::commit(const Scalar &v, const Scalar &v_blinding, uint8_t V32[32]) {
+    Variable var;
+    commit_batch(&v, &v_blinding, 1, V32, &var);
+    return var;
+}
+
+void Prover::commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, uint8_t *V32, Variable *vars) {
+    std::vector<sc> vr(2 * m);
+    for (size_t i = 0; i < m; i++) {
+        vr[2 * i] = v[i].v;
+        vr[2 * i + 1] = v_blinding[i].v;
+    }
+    int rc = pedersen_batch(gens_, vr.data(), m, V32);
+    if (rc) throw R1CSError(rc, "pedersen commitment kernel failed");
+    for (size_t i = 0; i < m; i++) {
+        vars[i] = Variable{VAR_COMMITTED, (uint32_t)v_.size()};
+        v_.push_back(v[i].v);
+        v_blinding_.push_back(v_blinding[i].v);
+        tr_.append_point("V", V32 + 32 * i);
+    }
+}
+
+Scalar Prover::eval(const LinearCombination &lc) const {
+    Scalar acc(0);
+    for (const auto &t : lc.terms) {
+        switch (t.var.kind) {
+            case VAR_LEFT: acc += t.coeff * Scalar(a_L_[t.var.index]); break;
+            case VAR_RIGHT: acc += t.coeff * Scalar(a_R_[t.var.index]); break;
+            case VAR_OUTPUT: acc += t.coeff * Scalar(a_O_[t.var.index]); break;
+            case VAR_COMMITTED: acc += t.coeff * Scalar(v_[t.var.index]); break;
+            default: acc += t.coeff; break;
+        }
+    }
+    return acc;
+}
+
+ConstraintSystem::Triple Prover::multiply(LinearCombination left, LinearCombination right) {
+    Scalar l = eval(left), r = eval(right), o = l * r;
+    uint32_t i = (uint32_t)a_L_.size();
+    Triple t{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
+    a_L_.push_back(l.v);
+    a_R_.push_back(r.v);
+    a_O_.push_back(o.v);
+    left.terms.push_back({t.l, -Scalar(1)});
+    right.terms.push_back({t.r, -Scalar(1)});
+    cs_.push(left);
+    cs_.push(right);
+    return t;
+}
+
+ConstraintSystem::Triple Prover::allocate_multiplier(const Scalar *left, const Scalar *right) {
+    if (!left || !right) throw R1CSError(BPG_EMISSING, "R1CSError::MissingAssignment");
+    uint32_t i = (uint32_t)a_L_.size();
+    a_L_.push_back(left->v);
+    a_R_.push_back(right->v);
+    a_O_.push_back(((*left) * (*right)).v);
+    return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
+}
+
+static inline size_t next_pow2(size_t n) {
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
+    const double t_start = now_ms();
+    bpg_ctx *ctx = gens_->ctx;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = a_L_.size(), m = v_.size();
+    const size_t np = next_pow2(n ? n : 1);
+    if (gens_->capacity < np) return BPG_EGENS;
+    size_t lg = 0;
+    while (((size_t)1 << lg) < np) lg++;
+
+    // ---- transcript RNG (host, sequential Keccak)
+    tr_.append_u64("m", m);
+    TranscriptRng rng = tr_.build_rng();
+    for (size_t i = 0; i < m; i++) {
+        uint8_t b[32];
+        sc_tobytes(b, v_blinding_[i]);
+        rng.rekey_with_witness_bytes("v_blinding", b, 32);
+    }
+    uint8_t ext[32];
+    rng_fn(rng_user, ext, 32);
+    rng.finalize(ext);
+    const double t0 = now_ms();
+    sc i_bl = rng.scalar(), o_bl = rng.scalar(), s_bl = rng.scalar();
+    std::vector<sc> s_L(n), s_R(n);
+    for (size_t i = 0; i < n; i++) s_L[i] = rng.scalar();
+    for (size_t i = 0; i < n; i++) s_R[i] = rng.scalar();
+    timing.rng_ms = now_ms() - t0;
+
+    // ---- device workspace
+    FlatPlan fp;
+    build_flat_plan(cs_, (uint32_t)n, (uint32_t)m, false, fp);
+    const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
+    const size_t nblk_n = grid256(n ? n : 1), nblk_np = grid256(np);
+    size_t need = pad256(3 * N1 * 32) + 5 * pad256((n + 1) * 32) + pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) +
+                  4 * pad256((n + 1) * 32) + pad256(nblk_n * 6 * 32) + 2 * pad256(32 * 32) + 4 * pad256(np * 32) +
+                  pad256(2 * NR * 32) + pad256(nblk_np * 2 * 32) + (1 << 16);
+    Arena ar(ctx);
+    int rc = ar.reserve(need);
+    if (rc) return rc;
+    sc *d_rows = ar.take<sc>(3 * N1);
+    sc *d_aL = d_rows + 1, *d_aR = d_rows + 1 + n;             // row 0 = [i_bl | a_L | a_R]
+    sc *d_aO = d_rows + N1 + 1;                                 // row 1 = [o_bl | a_O | 0]
+    sc *d_sL = d_rows + 2 * N1 + 1, *d_sR = d_rows + 2 * N1 + 1 + n;   // row 2 = [s_bl | s_L | s_R]
+    BPG_CHECK_HIP(hipMemsetAsync(d_rows, 0, 3 * N1 * 32, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_rows, &i_bl, 32, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_rows + N1, &o_bl, 32, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_rows + 2 * N1, &s_bl, 32, hipMemcpyHostToDevice, s));
+    if (n) {
+        BPG_CHECK_HIP(hipMemcpyAsync(d_aL, a_L_.data(), n * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_aR, a_R_.data(), n * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_aO, a_O_.data(), n * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_sL, s_L.data(), n * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(d_sR, s_R.data(), n * 32, hipMemcpyHostToDevice, s));
+    }
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+
+    // ---- A_I1, A_O1, S1: one 3-target MSM over [B~ | G[0..n) | H[0..n)]
+    const double t1 = now_ms();
+    {
+        size_t st[3] = {gens_->off_Bb(), gens_->off_G(), gens_->off_H()}, ln[3] = {1, n, n};
+        bpg_msm_job *job = nullptr;
+        if ((rc = msm_submit(ctx, gens_->table, st, ln, 3, d_rows, N1, 3, false, &job))) return rc;
+        uint8_t out[96];
+        if ((rc = msm_wait(job, out, false))) return rc;
+        memcpy(P.A_I1, out, 32);
+        memcpy(P.A_O1, out + 32, 32);
+        memcpy(P.S1, out + 64, 32);
+    }
+    timing.commit_ms = now_ms() - t1;
+    tr_.append_point("A_I1", P.A_I1);
+    tr_.append_point("A_O1", P.A_O1);
+    tr_.append_point("S1", P.S1);
+    tr_.r1cs_1phase_domain_sep();          // the reference's gadgets register no randomized constraints
+    memset(P.A_I2, 0, 32);
+    memset(P.A_O2, 0, 32);
+    memset(P.S2, 0, 32);
+    tr_.append_point("A_I2", P.A_I2);
+    tr_.append_point("A_O2", P.A_O2);
+    tr_.append_point("S2", P.S2);
+    const Scalar y = tr_.challenge_scalar("y"), z = tr_.challenge_scalar("z");
+
+    // ---- flatten, l/r polynomials, t coefficients
+    const double t2 = now_ms();
+    sc *d_W = ar.take<sc>(fp.nslots + 1);
+    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W))) return rc;
+    sc ytbl[32], yinvtbl[32];
+    const Scalar y_inv = y.invert();
+    pow2_table(ytbl, y.v);
+    pow2_table(yinvtbl, y_inv.v);
+    sc *d_ytbl = ar.take<sc>(32), *d_yinvtbl = ar.take<sc>(32);
+    BPG_CHECK_HIP(hipMemcpyAsync(d_ytbl, ytbl, sizeof ytbl, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_yinvtbl, yinvtbl, sizeof yinvtbl, hipMemcpyHostToDevice, s));
+    sc *d_l1 = ar.take<sc>(n + 1), *d_r0 = ar.take<sc>(n + 1), *d_r1 = ar.take<sc>(n + 1), *d_r3 = ar.take<sc>(n + 1);
+    sc *d_part = ar.take<sc>(nblk_n * 6);
+    std::vector<sc> h_part(nblk_n * 6), wV(m);
+    Scalar t[7];
+    if (n) {
+        hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n), dim3(256), 0, s, (uint32_t)n, d_aL, d_aR, d_aO, d_sL, d_sR, d_W, d_ytbl,
+                           d_yinvtbl, d_l1, d_r0, d_r1, d_r3, d_part);
+        BPG_CHECK_HIP(hipGetLastError());
+        BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
+    }
+    if (m) BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    if (n)
+        for (size_t b = 0; b < nblk_n; b++)
+            for (int k = 0; k < 6; k++) t[k + 1] += Scalar(h_part[b * 6 + k]);
+
+    // ---- T_1, T_3..T_6
+    Scalar tb[7];
+    tb[1] = rng.scalar(); tb[3] = rng.scalar(); tb[4] = rng.scalar(); tb[5] = rng.scalar(); tb[6] = rng.scalar();
+    {
+        sc vr[10] = {t[1].v, tb[1].v, t[3].v, tb[3].v, t[4].v, tb[4].v, t[5].v, tb[5].v, t[6].v, tb[6].v};
+        uint8_t Ts[160];
+        if ((rc = pedersen_batch(gens_, vr, 5, Ts))) return rc;
+        memcpy(P.T_1, Ts, 32); memcpy(P.T_3, Ts + 32, 32); memcpy(P.T_4, Ts + 64, 32);
+        memcpy(P.T_5, Ts + 96, 32); memcpy(P.T_6, Ts + 128, 32);
+    }
+    tr_.append_point("T_1", P.T_1);
+    tr_.append_point("T_3", P.T_3);
+    tr_.append_point("T_4", P.T_4);
+    tr_.append_point("T_5", P.T_5);
+    tr_.append_point("T_6", P.T_6);
+    const Scalar u = tr_.challenge_scalar("u"), x = tr_.challenge_scalar("x");
+    for (size_t j = 0; j < m; j++) tb[2] += Scalar(wV[j]) * Scalar(v_blinding_[j]);
+    P.t_x = x * (t[1] + x * (t[2] + x * (t[3] + x * (t[4] + x * (t[5] + x * t[6])))));
+    P.t_x_blinding = x * (tb[1] + x * (tb[2] + x * (tb[3] + x * (tb[4] + x * (tb[5] + x * tb[6])))));
+    P.e_blinding = x * (Scalar(i_bl) + x * (Scalar(o_bl) + x * Scalar(s_bl)));   // second-phase blindings are zero
+    tr_.append_scalar("t_x", P.t_x.v);
+    tr_.append_scalar("t_x_blinding", P.t_x_blinding.v);
+    tr_.append_scalar("e_blinding", P.e_blinding.v);
+    const Scalar w = tr_.challenge_scalar("w");
+
+    // ---- l(x), r(x) -> IPP vectors
+    sc *d_a = ar.take<sc>(np), *d_b = ar.take<sc>(np), *d_sG = ar.take<sc>(np), *d_sH = ar.take<sc>(np);
+    hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, x.v, u.v, d_l1, d_aO, d_sL,
+                       d_r0, d_r1, d_r3, d_ytbl, d_yinvtbl, d_a, d_b, d_sG, d_sH);
+    BPG_CHECK_HIP(hipGetLastError());
+    timing.poly_ms = now_ms() - t2;
+
+    // ---- inner-product argument, fold-free
+    const double t3 = now_ms();
+    tr_.innerproduct_domain_sep(np);
+    sc *d_rowLR = ar.take<sc>(2 * NR), *d_cpart = ar.take<sc>(nblk_np * 2);
+    P.L_vec.assign(32 * lg, 0);
+    P.R_vec.assign(32 * lg, 0);
+    size_t nk = np;
+    for (size_t k = 0; k < lg; k++, nk >>= 1) {
+        hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, d_a, d_b, d_sG, d_sH,
+                           d_rowLR, d_rowLR + NR, d_cpart);
+        hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, d_cpart, (uint32_t)nblk_np, w.v, d_rowLR + 2 * np,
+                           d_rowLR + NR + 2 * np);
+        BPG_CHECK_HIP(hipGetLastError());
+        BPG_CHECK_HIP(hipStreamSynchronize(s));
+        size_t st[3] = {gens_->off_G(), gens_->off_H(), gens_->off_B()}, ln[3] = {np, np, 1};
+        bpg_msm_job *job = nullptr;
+        if ((rc = msm_submit(ctx, gens_->table, st, ln, 3, d_rowLR, NR, 2, false, &job))) return rc;
+        uint8_t out[64];
+        if ((rc = msm_wait(job, out, false))) return rc;
+        memcpy(&P.L_vec[32 * k], out, 32);
+        memcpy(&P.R_vec[32 * k], out + 32, 32);
+        tr_.append_point("L", out);
+        tr_.append_point("R", out + 32);
+        const Scalar uk = tr_.challenge_scalar("u"), uk_inv = uk.invert();
+        hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, uk.v, uk_inv.v, d_a,
+                           d_b, d_sG, d_sH);
+        BPG_CHECK_HIP(hipGetLastError());
+    }
+    sc ha, hb;
+    BPG_CHECK_HIP(hipMemcpyAsync(&ha, d_a, 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(&hb, d_b, 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    P.a = Scalar(ha);
+    P.b = Scalar(hb);
+    timing.ipp_ms = now_ms() - t3;
+    timing.total_ms = now_ms() - t_start;
+    return BPG_OK;
+}
+
+// =================================================================== Verifier
+
+Verifier::Verifier(const void *label, size_t label_len) : tr_(label, label_len) { tr_.r1cs_domain_sep(); }
+
+Variable Verifier::commit(const uint8_t V32[32]) {
+    uint32_t i = (uint32_t)(V_.size() / 32);
+    V_.insert(V_.end(), V32, V32 + 32);
+    tr_.append_point("V", V32);
+    return Variable{VAR_COMMITTED, i};
+}
+
+ConstraintSystem::Triple Verifier::multiply(LinearCombination left, LinearCombination right) {
+    uint32_t i = (uint32_t)num_vars_++;
+    Triple t{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
+    left.terms.push_back({t.l, -Scalar(1)});
+    right.terms.push_back({t.r, -Scalar(1)});
+    cs_.push(left);
+    cs_.push(right);
+    return t;
+}
+
+ConstraintSystem::Triple Verifier::allocate_multiplier(const Scalar *, const Scalar *) {
+    uint32_t i = (uint32_t)num_vars_++;
+    return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
+}
+
+int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
+    bpg_ctx *ctx = gens->ctx;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t n = num_vars_, m = V_.size() / 32;
+    const size_t np = next_pow2(n ? n : 1);
+    size_t lg = 0;
+    while (((size_t)1 << lg) < np) lg++;
+    tr_.append_u64("m", m);
+    if (!tr_.validate_and_append_point("A_I1", P.A_I1) || !tr_.validate_and_append_point("A_O1", P.A_O1) ||
+        !tr_.validate_and_append_point("S1", P.S1))
+        return BPG_EVERIFY;
+    tr_.r1cs_1phase_domain_sep();
+    if (gens->capacity < np) return BPG_EGENS;
+    tr_.append_point("A_I2", P.A_I2);
+    tr_.append_point("A_O2", P.A_O2);
+    tr_.append_point("S2", P.S2);
+    const Scalar y = tr_.challenge_scalar("y"), z = tr_.challenge_scalar("z");
+    if (!tr_.validate_and_append_point("T_1", P.T_1) || !tr_.validate_and_append_point("T_3", P.T_3) ||
+        !tr_.validate_and_append_point("T_4", P.T_4) || !tr_.validate_and_append_point("T_5", P.T_5) ||
+        !tr_.validate_and_append_point("T_6", P.T_6))
+        return BPG_EVERIFY;
+    const Scalar u = tr_.challenge_scalar("u"), x = tr_.challenge_scalar("x");
+    tr_.append_scalar("t_x", P.t_x.v);
+    tr_.append_scalar("t_x_blinding", P.t_x_blinding.v);
+    tr_.append_scalar("e_blinding", P.e_blinding.v);
+    const Scalar w = tr_.challenge_scalar("w");
+    // IPP verification scalars
+    if (P.L_vec.size() != 32 * lg || P.R_vec.size() != 32 * lg || lg >= 32) return BPG_EVERIFY;
+    tr_.innerproduct_domain_sep(np);
+    std::vector<sc> uk(lg + 1), ukinv(lg + 1), u_sq(lg), u_inv_sq(lg);
+    for (size_t k = 0; k < lg; k++) {
+        if (!tr_.validate_and_append_point("L", &P.L_vec[32 * k]) || !tr_.validate_and_append_point("R", &P.R_vec[32 * k]))
+            return BPG_EVERIFY;
+        Scalar c = tr_.challenge_scalar("u"), ci = c.invert();
+        uk[k] = c.v;
+        ukinv[k] = ci.v;
+        u_sq[k] = (c * c).v;
+        u_inv_sq[k] = (ci * ci).v;
+    }
+    // external randomness -> r
+    TranscriptRng rng = tr_.build_rng();
+    uint8_t ext[32];
+    rng_fn(rng_user, ext, 32);
+    rng.finalize(ext);
+    const Scalar r = rng.scalar();
+
+    // per-proof points -> scratch region of the generator table: [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T.. | L.. | R..]
+    const size_t ndyn = 6 + m + 5 + 2 * lg;
+    if (ndyn > gens->dyn_capacity) return BPG_EGENS;
+    std::vector<uint8_t> dyn;
+    dyn.reserve(32 * ndyn);
+    auto put = [&](const uint8_t *p) { dyn.insert(dyn.end(), p, p + 32); };
+    put(P.A_I1); put(P.A_O1); put(P.S1); put(P.A_I2); put(P.A_O2); put(P.S2);
+    dyn.insert(dyn.end(), V_.begin(), V_.end());
+    put(P.T_1); put(P.T_3); put(P.T_4); put(P.T_5); put(P.T_6);
+    dyn.insert(dyn.end(), P.L_vec.begin(), P.L_vec.end());
+    dyn.insert(dyn.end(), P.R_vec.begin(), P.R_vec.end());
+    uint32_t bad = 0;
+    int rc = table_write_compressed(ctx, gens->table->d_table + gens->off_dyn(), dyn.data(), ndyn, &bad);
+    if (rc) return rc;
+    if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
+
+    FlatPlan fp;
+    build_flat_plan(cs_, (uint32_t)n, (uint32_t)m, true, fp);
+    const size_t NS = 2 * np + 2 + ndyn, nblk = grid256(np);
+    size_t need = pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) + pad256(32 * 32) + 2 * pad256((lg + 1) * 32) +
+                  pad256(NS * 32) + pad256(nblk * 32) + (1 << 16);
+    Arena ar(ctx);
+    if ((rc = ar.reserve(need))) return rc;
+    sc *d_W = ar.take<sc>(fp.nslots + 1);
+    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W))) return rc;
+    sc yinvtbl[32];
+    pow2_table(yinvtbl, y.invert().v);
+    sc *d_yinvtbl = ar.take<sc>(32), *d_uk = ar.take<sc>(lg + 1), *d_ukinv = ar.take<sc>(lg + 1);
+    sc *d_sc = ar.take<sc>(NS), *d_part = ar.take<sc>(nblk);
+    BPG_CHECK_HIP(hipMemcpyAsync(d_yinvtbl, yinvtbl, sizeof yinvtbl, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_uk, uk.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(d_ukinv, ukinv.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
+    verify_args A{x.v, P.a.v, P.b.v, u.v, (uint32_t)n, (uint32_t)np, (uint32_t)lg};
+    // scalar row order = table order: [ g (G) | h (H) | B | B~ | dyn ]
+    hipLaunchKernelGGL(k_verify_scalars, dim3((unsigned)nblk), dim3(256), 0, s, A, d_W, d_yinvtbl, d_uk, d_ukinv, d_sc, d_sc + np,
+                       d_part);
+    BPG_CHECK_HIP(hipGetLastError());
+    std::vector<sc> h_part(nblk), wV(m + 1);
+    BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk * 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, (m + 1) * 32, hipMemcpyDeviceToHost, s));   // wV | wc
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    Scalar delta(0);
+    for (size_t b = 0; b < nblk; b++) delta += Scalar(h_part[b]);
+    const Scalar wc(wV[m]);
+    const Scalar xx = x * x, rxx = r * xx, xxx = x * xx, ab = P.a * P.b;
+    std::vector<sc> tail;
+    tail.reserve(2 + ndyn);
+    tail.push_back((w * (P.t_x - ab) + r * (xx * (wc + delta) - P.t_x)).v);      // B
+    tail.push_back((-P.e_blinding - r * P.t_x_blinding).v);                       // B~
+    tail.push_back(x.v); tail.push_back(xx.v); tail.push_back(xxx.v);             // A_I1 A_O1 S1
+    tail.push_back((u * x).v); tail.push_back((u * xx).v); tail.push_back((u * xxx).v);   // A_I2 A_O2 S2
+    for (size_t j = 0; j < m; j++) tail.push_back((Scalar(wV[j]) * rxx).v);       // V
+    tail.push_back((r * x).v); tail.push_back((rxx * x).v); tail.push_back((rxx * xx).v);
+    tail.push_back((rxx * xxx).v); tail.push_back((rxx * xx * xx).v);             // T_1 T_3 T_4 T_5 T_6
+    for (size_t k = 0; k < lg; k++) tail.push_back(u_sq[k]);                      // L
+    for (size_t k = 0; k < lg; k++) tail.push_back(u_inv_sq[k]);                  // R
+    BPG_CHECK_HIP(hipMemcpyAsync(d_sc + 2 * np, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    size_t st[3] = {gens->off_G(), gens->off_H(), gens->off_B()}, ln[3] = {np, np, 2 + ndyn};
+    bpg_msm_job *job = nullptr;
+    if ((rc = msm_submit(ctx, gens->table, st, ln, 3, d_sc, NS, 1, false, &job))) return rc;
+    uint8_t out[32];
+    if ((rc = msm_wait(job, out, false))) return rc;
+    uint8_t acc = 0;
+    for (int i = 0; i < 32; i++) acc |= out[i];
+    return acc ? BPG_EVERIFY : BPG_OK;
+}
+
+}  // namespace bpg

@@ -1,0 +1,367 @@
+"""Host-side Python mirror of the R1CS layer of libbpg.so (include/bpg.h, second half).
+
+Same names and argument meaning as the Rust API the reference calls
+(`Prover`, `Verifier`, `LinearCombination`, `Variable`, `BulletproofGens`,
+`SonnyEdwardsPointGadget`, `SonnyRistrettoPointGadget`, the gadget functions), so
+that the parity tests read like the reference's own tests.  Every method is one
+call through the C ABI; nothing is computed here.
+"""
+import ctypes
+
+from . import _native
+from ._native import BpgError, check, lib
+
+L = 2**252 + 27742317777372353535851937790883648493
+KIND_COMMITTED, KIND_LEFT, KIND_RIGHT, KIND_OUTPUT, KIND_ONE = 0, 1, 2, 3, 4
+ONE_VAR = KIND_ONE << 32
+
+
+class VerificationError(Exception):
+    """R1CSError::VerificationError"""
+
+
+def _sc(x):
+    return (int(x) % L).to_bytes(32, "little")
+
+
+class Variable:
+    __slots__ = ("code",)
+
+    def __init__(self, code):
+        self.code = int(code)
+
+    def _lc(self):
+        return LinearCombination([(self.code, 1)])
+
+    def __add__(self, o):
+        return self._lc() + o
+
+    def __radd__(self, o):
+        return LinearCombination.of(o) + self
+
+    def __sub__(self, o):
+        return self._lc() - o
+
+    def __rsub__(self, o):
+        return LinearCombination.of(o) - self
+
+    def __neg__(self):
+        return -self._lc()
+
+
+class LinearCombination:
+    __slots__ = ("terms",)
+
+    def __init__(self, terms=None):
+        self.terms = list(terms or [])
+
+    @staticmethod
+    def of(x):
+        if isinstance(x, LinearCombination):
+            return x
+        if isinstance(x, Variable):
+            return LinearCombination([(x.code, 1)])
+        return LinearCombination([(ONE_VAR, int(x) % L)])
+
+    def clone(self):
+        return LinearCombination(self.terms)
+
+    def __add__(self, o):
+        return LinearCombination(self.terms + LinearCombination.of(o).terms)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return LinearCombination(self.terms + [(v, (-c) % L) for v, c in LinearCombination.of(o).terms])
+
+    def __rsub__(self, o):
+        return LinearCombination.of(o) - self
+
+    def __neg__(self):
+        return LinearCombination([(v, (-c) % L) for v, c in self.terms])
+
+    def marshal(self):
+        n = len(self.terms)
+        vars_ = (ctypes.c_uint64 * max(n, 1))(*[v for v, _ in self.terms])
+        coeffs = b"".join(_sc(c) for _, c in self.terms)
+        return vars_, coeffs, n
+
+
+LC = LinearCombination
+
+
+def _rng_cb(data):
+    """bpg_rng_fn that hands out `data` (the external randomness, e.g. 32 bytes from a seeded stream)."""
+    state = {"pos": 0}
+
+    def fn(_user, out, n):
+        chunk = data[state["pos"]:state["pos"] + n]
+        chunk = chunk + bytes(n - len(chunk))
+        state["pos"] += n
+        ctypes.memmove(out, chunk, n)
+    return _native.RNG_FN(fn)
+
+
+class BulletproofGens:
+    """BulletproofGens::new(capacity, 1) + PedersenGens::default(), resident on the context's GPU."""
+
+    def __init__(self, ctx, gens_capacity, max_commitments=4096):
+        self.ctx, self.gens_capacity = ctx, gens_capacity
+        h = ctypes.c_void_p()
+        check(lib().bpg_gens_create(ctx._h, gens_capacity, max_commitments, ctypes.byref(h)))
+        self._h = h.value
+
+    def export(self, which, start=0, n=1):
+        out = ctypes.create_string_buffer(32 * n)
+        check(lib().bpg_gens_export(self.ctx._h, self._h, ord(which), start, n, out))
+        return out.raw
+
+    def free(self):
+        if self._h:
+            lib().bpg_gens_free(self._h)
+            self._h = None
+
+
+class Proof:
+    def __init__(self, raw):
+        self.raw = raw
+
+    def to_bytes(self):
+        return self.raw
+
+
+class _CS:
+    def _triple(self, out):
+        return Variable(out[0]), Variable(out[1]), Variable(out[2])
+
+    def multiply(self, left, right):
+        lv, lc, nl = LinearCombination.of(left).marshal()
+        rv, rc, nr = LinearCombination.of(right).marshal()
+        out = (ctypes.c_uint64 * 3)()
+        check(lib().bpg_cs_multiply(self._cs, lv, lc, nl, rv, rc, nr, out))
+        return self._triple(out)
+
+    def allocate_multiplier(self, assignment):
+        out = (ctypes.c_uint64 * 3)()
+        if assignment is None:
+            check(lib().bpg_cs_allocate_multiplier(self._cs, None, None, out))
+        else:
+            check(lib().bpg_cs_allocate_multiplier(self._cs, _sc(assignment[0]), _sc(assignment[1]), out))
+        return self._triple(out)
+
+    def constrain(self, lc):
+        v, c, n = LinearCombination.of(lc).marshal()
+        check(lib().bpg_cs_constrain(self._cs, v, c, n))
+
+
+class Prover(_CS):
+    def __init__(self, gens, label):
+        self.gens = gens
+        h = ctypes.c_void_p()
+        check(lib().bpg_prover_new(gens._h, label, len(label), ctypes.byref(h)))
+        self._h = h.value
+        self._cs = lib().bpg_prover_cs(self._h)
+
+    def commit(self, v, v_blinding):
+        V = ctypes.create_string_buffer(32)
+        var = ctypes.c_uint64()
+        check(lib().bpg_prover_commit(self._h, _sc(v), _sc(v_blinding), V, ctypes.byref(var)))
+        return V.raw, Variable(var.value)
+
+    def commit_batch(self, values, blindings):
+        m = len(values)
+        V = ctypes.create_string_buffer(32 * max(m, 1))
+        vars_ = (ctypes.c_uint64 * max(m, 1))()
+        check(lib().bpg_prover_commit_batch(self._h, b"".join(_sc(x) for x in values), b"".join(_sc(x) for x in blindings), m, V, vars_))
+        return [V.raw[32 * i:32 * i + 32] for i in range(m)], [Variable(vars_[i]) for i in range(m)]
+
+    def prove(self, bp_gens=None, external_rng32=bytes(32)):
+        assert bp_gens is None or bp_gens is self.gens
+        cb = _rng_cb(external_rng32)
+        cap = 1 << 16
+        out = ctypes.create_string_buffer(cap)
+        n = ctypes.c_size_t()
+        check(lib().bpg_prover_prove(self._h, cb, None, out, cap, ctypes.byref(n)))
+        return Proof(out.raw[:n.value])
+
+    def stats(self):
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().bpg_prover_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def timing(self):
+        t = (ctypes.c_double * 5)()
+        check(lib().bpg_prover_timing(self._h, t))
+        return dict(zip(("rng_ms", "commit_ms", "poly_ms", "ipp_ms", "total_ms"), t))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().bpg_prover_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Verifier(_CS):
+    def __init__(self, label):
+        h = ctypes.c_void_p()
+        check(lib().bpg_verifier_new(label, len(label), ctypes.byref(h)))
+        self._h = h.value
+        self._cs = lib().bpg_verifier_cs(self._h)
+
+    def commit(self, V32):
+        var = ctypes.c_uint64()
+        check(lib().bpg_verifier_commit(self._h, V32, ctypes.byref(var)))
+        return Variable(var.value)
+
+    def verify(self, proof, pc_gens, bp_gens, external_rng32=bytes(32)):
+        """Ok(()) -> True; Err(R1CSError::VerificationError) -> raises VerificationError"""
+        raw = proof.to_bytes() if hasattr(proof, "to_bytes") else bytes(proof)
+        cb = _rng_cb(external_rng32)
+        rc = lib().bpg_verifier_verify(self._h, bp_gens._h, raw, len(raw), cb, None)
+        if rc == _native.EVERIFY:
+            raise VerificationError()
+        check(rc)
+        return True
+
+    def stats(self):
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().bpg_verifier_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().bpg_verifier_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _xyzt(p):
+    return _sc(p.X) + _sc(p.Y) + _sc(p.Z) + _sc(p.T)
+
+
+class _PointGadget:
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def _new(cls, fn, *args):
+        h = ctypes.c_void_p()
+        check(fn(*args, ctypes.byref(h)))
+        return cls(h.value)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().bpg_point_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class SonnyEdwardsPointGadget(_PointGadget):
+    def __init__(self, X=None, Y=None, Z=None, T=None):
+        if Y is None:
+            super().__init__(X)
+            return
+        import types
+        h = ctypes.c_void_p()
+        check(lib().bpg_point_from_coords(_xyzt(types.SimpleNamespace(X=X, Y=Y, Z=Z, T=T)), ctypes.byref(h)))
+        super().__init__(h.value)
+
+    @classmethod
+    def from_point(cls, p):
+        return cls._new(lib().bpg_point_from_coords, _xyzt(p))
+
+    @classmethod
+    def from_vars(cls, vars_):
+        arr = (ctypes.c_uint64 * 4)(*[v.code for v in vars_])
+        return cls._new(lib().bpg_point_from_vars, arr)
+
+    def add(self, other, cs):
+        return self._new(lib().bpg_edwards_add, cs._cs, self._h, other._h)
+
+    def double(self, cs):
+        return self._new(lib().bpg_edwards_double, cs._cs, self._h)
+
+    def equal(self, other, cs):
+        check(lib().bpg_edwards_equal(cs._cs, self._h, other._h))
+
+    def satisfy_curve_eq(self, cs):
+        check(lib().bpg_edwards_satisfy_curve_eq(cs._cs, self._h))
+
+    def conditionally_select(self, bit, cs):
+        v, c, n = LinearCombination.of(bit).marshal()
+        return self._new(lib().bpg_edwards_conditionally_select, cs._cs, self._h, v, c, n)
+
+    @classmethod
+    def scalar_mul(cls, point, sk, cs):
+        arr = (ctypes.c_uint64 * max(len(sk), 1))(*[v.code for v in sk])
+        return cls._new(lib().bpg_edwards_scalar_mul, cs._cs, point._h, arr, len(sk))
+
+    @classmethod
+    def prover_commit_to_sonny_edwards_point(cls, prover, p, rng):
+        bl = b"".join(_sc(rng.scalar()) for _ in range(4))
+        V = ctypes.create_string_buffer(128)
+        h = ctypes.c_void_p()
+        check(lib().bpg_edwards_prover_commit(prover._h, _xyzt(p), bl, ctypes.byref(h), V))
+        return cls(h.value), [V.raw[32 * i:32 * i + 32] for i in range(4)]
+
+    @classmethod
+    def verifier_commit_to_sonny_edwards_point(cls, verifier, commitments):
+        return cls._new(lib().bpg_edwards_verifier_commit, verifier._h, b"".join(commitments), len(commitments))
+
+
+class SonnyRistrettoPointGadget(_PointGadget):
+    @classmethod
+    def from_point(cls, point, cs):
+        return cls._new(lib().bpg_ristretto_from_point, cs._cs, _xyzt(point.p))
+
+    @classmethod
+    def from_lcs(cls, gadget, n_lcs, cs):
+        return cls._new(lib().bpg_ristretto_from_lcs, cs._cs, gadget._h, n_lcs)
+
+    def add(self, cs, other):
+        return self._new(lib().bpg_ristretto_add, cs._cs, self._h, other._h)
+
+    def double(self, cs):
+        return self._new(lib().bpg_ristretto_double, cs._cs, self._h)
+
+    def equals(self, cs, other):
+        check(lib().bpg_ristretto_equals(cs._cs, self._h, other._h))
+
+    def conditionally_select(self, bit, cs):
+        v, c, n = LinearCombination.of(bit).marshal()
+        return self._new(lib().bpg_ristretto_conditionally_select, cs._cs, self._h, v, c, n)
+
+
+def binary_constrain_gadget(cs, bit):
+    check(lib().bpg_gadget_binary_constrain(cs._cs, bit.code))
+
+
+def nonzero_gadget(var, var_assignment, cs):
+    """raises RuntimeError where the reference panics (zero assignment)"""
+    v, c, n = LinearCombination.of(var).marshal()
+    rc = lib().bpg_gadget_nonzero(cs._cs, v, c, n, None if var_assignment is None else _sc(var_assignment))
+    if rc == _native.EGADGET:
+        raise RuntimeError((lib().bpg_last_error() or b"").decode())
+    check(rc)
+
+
+def sk_knowledge_gadget(cs, basep, pk, sk):
+    arr = (ctypes.c_uint64 * max(len(sk), 1))(*[v.code for v in sk])
+    check(lib().bpg_sk_knowledge_gadget(cs._cs, basep._h, pk._h, arr, len(sk)))
+
+
+def transcript_kat(label, msg_label, msg, challenge_label, n):
+    out = ctypes.create_string_buffer(n)
+    check(lib().bpg_transcript_kat(label, len(label), msg_label, msg, len(msg), challenge_label, out, n))
+    return out.raw
+
+
+__all__ = ["BpgError", "BulletproofGens", "LinearCombination", "LC", "Variable", "Prover", "Verifier", "Proof",
+           "VerificationError", "SonnyEdwardsPointGadget", "SonnyRistrettoPointGadget", "binary_constrain_gadget",
+           "nonzero_gadget", "sk_knowledge_gadget", "transcript_kat"]

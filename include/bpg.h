@@ -116,6 +116,101 @@ int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int
  * the most recently *waited* job, measured with HIP events on the job's stream. */
 int bpg_msm_last_kernel_us(bpg_ctx *ctx, float *accumulate_us, float *total_device_us);
 
+/* ======================================================================================
+ * R1CS layer: the bulletproofs::r1cs API the reference's gadgets and tests call.
+ *
+ * Variables cross the ABI as uint64 = kind << 32 | index with kind 0 = Committed,
+ * 1 = MultiplierLeft, 2 = MultiplierRight, 3 = MultiplierOutput, 4 = One
+ * (bulletproofs::r1cs::Variable).  A LinearCombination crosses as parallel arrays
+ * (vars[n], coeffs[n][32]).  External randomness is injected through bpg_rng_fn,
+ * as the reference injects `&mut thread_rng()` (ref: tests/edwards_point.rs:31,79).
+ * ====================================================================================== */
+typedef struct bpg_gens bpg_gens;               /* PedersenGens::default() + BulletproofGens::new(cap, 1), resident in HBM */
+typedef struct bpg_prover bpg_prover;           /* r1cs::Prover (owns its Transcript)  */
+typedef struct bpg_verifier bpg_verifier;       /* r1cs::Verifier (owns its Transcript) */
+typedef struct bpg_cs bpg_cs;                   /* &mut dyn ConstraintSystem: a Prover or a Verifier */
+typedef struct bpg_point_gadget bpg_point_gadget; /* Sonny{Edwards,Ristretto}PointGadget {X, Y, Z, T: LC} */
+typedef void (*bpg_rng_fn)(void *user, uint8_t *out, size_t n);
+
+/* BulletproofGens::new(gens_capacity, 1) + PedersenGens::default()
+ * (ref: tests/edwards_point.rs:89-90,167-168,252-253,285-286,366-367; scalar.rs:69-70; sk_know_gadget.rs:94-95).
+ * max_commitments bounds the number of high-level commitments a verified proof may carry. */
+int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t max_commitments, bpg_gens **out);
+void bpg_gens_free(bpg_gens *gens);
+size_t bpg_gens_capacity(const bpg_gens *gens);
+/* compress generators: which = 'G' | 'H' (party-0 share), 'B' (pc_gens.B), 'b' (pc_gens.B_blinding) */
+int bpg_gens_export(bpg_ctx *ctx, const bpg_gens *gens, int which, size_t start, size_t n, uint8_t *out32);
+
+/* Transcript::new(label) + Prover::new(&pc_gens, &mut transcript)   ref: tests/edwards_point.rs:25-28 */
+int bpg_prover_new(bpg_gens *gens, const uint8_t *label, size_t label_len, bpg_prover **out);
+void bpg_prover_free(bpg_prover *p);
+bpg_cs *bpg_prover_cs(bpg_prover *p);
+/* Prover::commit(v, v_blinding) -> (CompressedRistretto, Variable)   ref: edwards_point.rs:267; tests/edwards_point.rs:31 */
+int bpg_prover_commit(bpg_prover *p, const uint8_t v32[32], const uint8_t blinding32[32], uint8_t V32[32], uint64_t *var);
+/* m commits in transcript order with one kernel launch (ref: sk_know_gadget.rs:52-55 commits 256 bits one by one) */
+int bpg_prover_commit_batch(bpg_prover *p, const uint8_t *v32, const uint8_t *blinding32, size_t m, uint8_t *V32, uint64_t *vars);
+/* Prover::prove(&bp_gens) -> R1CSProof::to_bytes()   ref: tests/edwards_point.rs:47,134,215,320,391; scalar.rs:46; sk_know_gadget.rs:63
+ * Returns BPG_EGENS for R1CSError::InvalidGeneratorsLength.  *proof_len is set even when cap is too small (BPG_EINVAL). */
+int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *proof_out, size_t cap, size_t *proof_len);
+int bpg_prover_stats(const bpg_prover *p, size_t *multipliers, size_t *constraints);
+/* milliseconds of the last prove(): blinding RNG, A/S commitments, polynomial phase, inner-product argument, total */
+int bpg_prover_timing(const bpg_prover *p, double out_ms[5]);
+
+/* Transcript::new(label) + Verifier::new(&mut transcript)   ref: tests/edwards_point.rs:59-61 */
+int bpg_verifier_new(const uint8_t *label, size_t label_len, bpg_verifier **out);
+void bpg_verifier_free(bpg_verifier *v);
+bpg_cs *bpg_verifier_cs(bpg_verifier *v);
+/* Verifier::commit(V) -> Variable   ref: edwards_point.rs:283; tests/edwards_point.rs:63 */
+int bpg_verifier_commit(bpg_verifier *v, const uint8_t V32[32], uint64_t *var);
+/* Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng)   ref: tests/edwards_point.rs:79,158,242,345,412; scalar.rs:63; sk_know_gadget.rs:86
+ * BPG_OK | BPG_EVERIFY (R1CSError::VerificationError) | BPG_EFORMAT | BPG_EGENS */
+int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, size_t proof_len, bpg_rng_fn rng, void *rng_user);
+int bpg_verifier_stats(const bpg_verifier *v, size_t *multipliers, size_t *constraints);
+
+/* ConstraintSystem::multiply / allocate_multiplier / constrain
+ * (ref: edwards_point.rs:45-85; scalar.rs:10-21; boolean.rs:16,20).  out = (left, right, output) variables.
+ * allocate_multiplier with NULL assignments on a prover returns BPG_EMISSING (R1CSError::MissingAssignment). */
+int bpg_cs_multiply(bpg_cs *cs, const uint64_t *lvars, const uint8_t *lcoeffs, size_t nl, const uint64_t *rvars,
+                    const uint8_t *rcoeffs, size_t nr, uint64_t out[3]);
+int bpg_cs_allocate_multiplier(bpg_cs *cs, const uint8_t *left32, const uint8_t *right32, uint64_t out[3]);
+int bpg_cs_constrain(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n);
+
+/* The reference's gadget library (same circuits, call for call). */
+int bpg_gadget_binary_constrain(bpg_cs *cs, uint64_t bit_var);                      /* ref: src/gadgets/boolean.rs:12-21 */
+/* ref: src/gadgets/scalar.rs:9-26; BPG_EGADGET where the reference panics (zero assignment, :13-15) */
+int bpg_gadget_nonzero(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n, const uint8_t *assignment32);
+/* points cross as X | Y | Z | T, 32-byte little-endian Sonny field elements (zerocaf FieldElement::to_bytes) */
+int bpg_point_from_coords(const uint8_t xyzt128[128], bpg_point_gadget **out);      /* SonnyEdwardsPointGadget::from_point, edwards_point.rs:19-26 */
+int bpg_point_from_vars(const uint64_t vars[4], bpg_point_gadget **out);
+void bpg_point_free(bpg_point_gadget *p);
+int bpg_edwards_add(bpg_cs *cs, const bpg_point_gadget *a, const bpg_point_gadget *b, bpg_point_gadget **out);   /* edwards_point.rs:28-93 */
+int bpg_edwards_double(bpg_cs *cs, const bpg_point_gadget *a, bpg_point_gadget **out);                           /* :97-137 */
+int bpg_edwards_equal(bpg_cs *cs, const bpg_point_gadget *a, const bpg_point_gadget *b);                         /* :166-174 */
+int bpg_edwards_satisfy_curve_eq(bpg_cs *cs, const bpg_point_gadget *a);                                         /* :178-211 */
+int bpg_edwards_conditionally_select(bpg_cs *cs, const bpg_point_gadget *a, const uint64_t *bit_vars, const uint8_t *bit_coeffs,
+                                     size_t n, bpg_point_gadget **out);                                          /* :215-253 */
+int bpg_edwards_scalar_mul(bpg_cs *cs, const bpg_point_gadget *point, const uint64_t *sk_vars, size_t nbits,
+                           bpg_point_gadget **out);                                                              /* :140-163 */
+int bpg_edwards_prover_commit(bpg_prover *p, const uint8_t xyzt128[128], const uint8_t blindings128[128], bpg_point_gadget **out,
+                              uint8_t V128[128]);                                                                /* :255-276 */
+/* BPG_EGADGET unless n_commitments == 4 (the reference asserts, :282) */
+int bpg_edwards_verifier_commit(bpg_verifier *v, const uint8_t *V32, size_t n_commitments, bpg_point_gadget **out); /* :278-290 */
+int bpg_ristretto_from_point(bpg_cs *cs, const uint8_t xyzt128[128], bpg_point_gadget **out);                    /* ristretto_point.rs:23-32 */
+/* BPG_EGADGET unless n_lcs == 4 (the reference asserts, ristretto_point.rs:35) */
+int bpg_ristretto_from_lcs(bpg_cs *cs, const bpg_point_gadget *lcs, size_t n_lcs, bpg_point_gadget **out);       /* :34-45 */
+int bpg_ristretto_add(bpg_cs *cs, const bpg_point_gadget *a, const bpg_point_gadget *b, bpg_point_gadget **out); /* :92-168 */
+int bpg_ristretto_double(bpg_cs *cs, const bpg_point_gadget *a, bpg_point_gadget **out);                         /* :177-180 */
+int bpg_ristretto_equals(bpg_cs *cs, const bpg_point_gadget *a, const bpg_point_gadget *b);                      /* :171-175 */
+int bpg_ristretto_conditionally_select(bpg_cs *cs, const bpg_point_gadget *a, const uint64_t *bit_vars, const uint8_t *bit_coeffs,
+                                       size_t n, bpg_point_gadget **out);                                        /* :184-226 */
+int bpg_sk_knowledge_gadget(bpg_cs *cs, const bpg_point_gadget *basep, const bpg_point_gadget *pk, const uint64_t *sk_vars,
+                            size_t nbits);                                           /* ref: src/gadgets/sk_knowledge/sk_know_gadget.rs:13-38 */
+
+/* Merlin: Transcript::new(label); append_message(msg_label, msg); challenge_bytes(challenge_label) -> out.
+ * Exposed so the Fiat-Shamir layer can be checked against Merlin's published known-answer vector. */
+int bpg_transcript_kat(const uint8_t *label, size_t label_len, const char *msg_label, const uint8_t *msg, size_t msg_len,
+                       const char *challenge_label, uint8_t *out, size_t out_len);
+
 #ifdef __cplusplus
 }
 #endif

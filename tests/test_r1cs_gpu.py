@@ -1,0 +1,192 @@
+"""GPU: the R1CS path through the C ABI.
+
+1. The reference's verdict table (tests/edwards_point.rs, scalar.rs, sk_know_gadget.rs)
+   holds on the GPU prover + GPU verifier.
+2. Proof BYTES equal the oracle's under the same seeded RNG (integer work: byte equality),
+   for every reference circuit and for padded / unpadded sizes.
+3. Cross-verification: oracle verifies GPU proofs, GPU verifies oracle proofs.
+"""
+import random
+
+import pytest
+
+from oracle import r1cs as R
+from oracle import sonny
+from tests import ref_cases as rc
+from tests.backends import GpuBackend, OracleBackend
+
+pytestmark = pytest.mark.gpu
+L = sonny.L
+
+
+@pytest.fixture(scope="module")
+def gbe(gpu_ctx):
+    return GpuBackend(gpu_ctx)
+
+
+@pytest.fixture(scope="module")
+def obe(oracle):
+    return OracleBackend(oracle)
+
+
+@pytest.fixture()
+def rnd():
+    return random.Random(77)
+
+
+def test_generators_match_oracle(gbe, oracle):
+    g = gbe.bp_gens(128)
+    G, H = oracle.gens(128)
+    B, Bb = oracle.pedersen()
+    assert g.export("G", 0, 128) == oracle.encode(G, 128)
+    assert g.export("H", 0, 128) == oracle.encode(H, 128)
+    assert g.export("B") == oracle.encode(B, 1)
+    assert g.export("b") == oracle.encode(Bb, 1)
+
+
+def test_pedersen_commit_matches_oracle(gbe, obe, rnd):
+    gbe.bp_gens(128)
+    p = gbe.Prover(b"commit")
+    vals = [0, 1, L - 1, 2**252, rnd.randrange(L), rnd.randrange(L)]
+    bls = [0, L - 1, 1, rnd.randrange(L), rnd.randrange(L), 0]
+    Vs, _ = p.commit_batch(vals, bls)
+    for v, b, V in zip(vals, bls, Vs):
+        assert V == obe.pc_gens.commit(v, b)
+    V1, _ = p.commit(vals[4], bls[4])
+    assert V1 == Vs[4]
+
+
+def _both(case, gbe, obe, *args, seed=b"x", **kw):
+    ok_g, pg = case(gbe, *args, rng=R.SeededRng(seed), **kw)
+    ok_o, po = case(obe, *args, rng=R.SeededRng(seed), **kw)
+    assert ok_g == ok_o
+    assert pg.to_bytes() == po.to_bytes()
+    return ok_g
+
+
+def test_conditionally_select(gbe, obe, rnd):
+    P1, ID = sonny.random_point(rnd), sonny.EdwardsPoint.identity()
+    assert _both(rc.cond_selection_roundtrip, gbe, obe, P1, P1, 1)
+    assert not _both(rc.cond_selection_roundtrip, gbe, obe, P1, P1, 0)
+    assert _both(rc.cond_selection_roundtrip, gbe, obe, P1, ID, 0)
+    assert not _both(rc.cond_selection_roundtrip, gbe, obe, P1, ID, 1)
+
+
+def test_double_pub_points(gbe, obe, rnd):
+    p, bad = sonny.random_point(rnd), sonny.random_point(rnd)
+    assert _both(rc.double_roundtrip, gbe, obe, p, p.double())
+    assert not _both(rc.double_roundtrip, gbe, obe, p, bad)
+
+
+def test_add_pub_points(gbe, obe, rnd):
+    """BASELINE config 1 shape on the GPU: 16 multipliers (a power of two, no padding)"""
+    p1, p2, bad = (sonny.random_point(rnd) for _ in range(3))
+    assert _both(rc.addition_roundtrip, gbe, obe, p1, p2, p1 + p2)
+    assert not _both(rc.addition_roundtrip, gbe, obe, p1, p2, bad)
+
+
+def test_point_committing(gbe, obe, rnd):
+    A = sonny.random_point(rnd)
+    assert _both(rc.point_committing_roundtrip, gbe, obe, A, A)
+    assert not _both(rc.point_committing_roundtrip, gbe, obe, A, A + A)
+
+
+def test_point_curve_eq(gbe, obe, rnd):
+    assert _both(rc.curve_eq_roundtrip, gbe, obe, sonny.random_point(rnd))
+    assert not _both(rc.curve_eq_roundtrip, gbe, obe, sonny.EdwardsPoint(1, 1, 1, 1))
+
+
+def test_is_not_zero(gbe, obe, rnd):
+    assert _both(rc.is_not_zero_roundtrip, gbe, obe, 1)
+    assert _both(rc.is_not_zero_roundtrip, gbe, obe, rnd.randrange(1, L))
+    with pytest.raises(RuntimeError):
+        rc.is_not_zero_roundtrip(gbe, 0)
+
+
+def test_ristretto_add_134_multipliers(gbe, obe, rnd):
+    """BASELINE config 5 unit proof: 134 multipliers padded to 256"""
+    p1, p2 = sonny.RistrettoPoint(sonny.random_point(rnd)), sonny.RistrettoPoint(sonny.random_point(rnd))
+    assert _both(rc.ristretto_add_roundtrip, gbe, obe, p1, p2, p1 + p2)
+    assert not _both(rc.ristretto_add_roundtrip, gbe, obe, p1, p2, p1 + p1)
+
+
+def test_scalar_mul_gadget(gbe, obe, rnd):
+    """BASELINE config 3 shape, small: committed bits, 27 multipliers per bit"""
+    base = sonny.random_point(rnd)
+    bits = [1, 0, 1, 1, 0, 1]
+    k = sum(b << i for i, b in enumerate(bits))
+    assert _both(rc.scalar_mul_roundtrip, gbe, obe, base, bits, base * k)
+    assert not _both(rc.scalar_mul_roundtrip, gbe, obe, base, bits, base * (k + 1))
+    assert not _both(rc.scalar_mul_roundtrip, gbe, obe, base, [1, 0, 2, 1, 0, 1], base * k)
+
+
+def test_sk_knowledge_small_vs_oracle(gbe, obe, rnd):
+    basep = sonny.RISTRETTO_BASEPOINT
+    sk = 0b1011
+    assert _both(rc.sk_knowledge_roundtrip, gbe, obe, basep, basep * sk, sk, nbits=4, cap=256)
+    assert not _both(rc.sk_knowledge_roundtrip, gbe, obe, basep, basep, sk, nbits=4, cap=256)
+
+
+def test_sk_knowledge_256_bits(gbe, rnd):
+    """ref: sk_know_gadget.rs:110-124 at full size: 256 committed bits, 7506 multipliers, gens 8192"""
+    basep = sonny.RISTRETTO_BASEPOINT
+    sk = rnd.randrange(1, sonny.R_ORDER)
+    pk = basep * sk
+    assert rc.sk_knowledge_roundtrip(gbe, basep, pk, sk)[0]
+    assert not rc.sk_knowledge_roundtrip(gbe, basep, basep, sk)[0]
+    other = sonny.RistrettoPoint(sonny.random_point(rnd))
+    assert not rc.sk_knowledge_roundtrip(gbe, basep, other, sk)[0]
+
+
+def test_cross_verification(gbe, obe, rnd):
+    p1, p2 = sonny.random_point(rnd), sonny.random_point(rnd)
+    p3 = p1 + p2
+    _, proof_g = rc.addition_roundtrip(gbe, p1, p2, p3)
+    _, proof_o = rc.addition_roundtrip(obe, p1, p2, p3, rng=R.SeededRng(b"other"))
+
+    def circuit(be, cs):
+        g1, g2, g3 = (be.EdwardsGadget.from_point(p) for p in (p1, p2, p3))
+        g3.equal(g1.add(g2, cs), cs)
+    # oracle verifies the GPU proof
+    v = obe.Verifier(obe.Transcript(b"Point Addition"))
+    circuit(obe, v)
+    assert v.verify(R.R1CSProof.from_bytes(proof_g.to_bytes()), obe.pc_gens, obe.bp_gens(128), bytes(32))
+    # GPU verifies the oracle proof
+    bp = gbe.bp_gens(128)
+    v = gbe.Verifier(gbe.Transcript(b"Point Addition"))
+    circuit(gbe, v)
+    assert v.verify(proof_o, None, bp, bytes(32))
+
+
+def test_tampered_proofs_rejected(gbe, rnd):
+    p1, p2 = sonny.random_point(rnd), sonny.random_point(rnd)
+    p3 = p1 + p2
+    ok, proof = rc.addition_roundtrip(gbe, p1, p2, p3)
+    assert ok
+    raw = proof.to_bytes()
+    bp = gbe.bp_gens(128)
+    from bulletproofs_gadgets_amd import BpgError
+
+    def verify(b):
+        v = gbe.Verifier(gbe.Transcript(b"Point Addition"))
+        g1, g2, g3 = (gbe.EdwardsGadget.from_point(p) for p in (p1, p2, p3))
+        g3.equal(g1.add(g2, v), v)
+        try:
+            return v.verify(gbe.g.Proof(b), None, bp, bytes(32))
+        except (gbe.VerificationError, BpgError):
+            return False
+    assert verify(raw)
+    for off in range(1, len(raw), 32):
+        bad = bytearray(raw)
+        bad[off] ^= 1
+        assert not verify(bytes(bad)), off
+    assert not verify(raw[:-32])
+    assert not verify(b"\x02" + raw[1:])
+
+
+def test_generators_too_short(gbe, rnd):
+    from bulletproofs_gadgets_amd import BpgError, _native
+    p = sonny.random_point(rnd)
+    with pytest.raises(BpgError) as e:
+        rc.double_roundtrip(gbe, p, p.double(), cap=8)
+    assert e.value.code == _native.EGENS
