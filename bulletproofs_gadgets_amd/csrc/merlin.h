@@ -24,24 +24,42 @@ inline void keccak_f1600(uint64_t s[25]) {
         0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
         0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    // rho offsets indexed [x + 5y]
-    static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    // The prover's blinding RNG is one Keccak chain of ~2n permutations (one per drawn
+    // scalar), so this is written with the state in locals and every index constant.
+    uint64_t a[25];
+    for (int i = 0; i < 25; i++) a[i] = s[i];
+#define BPG_RHOPI(dst, src, r) b[dst] = (r) ? rotl64(a[src], (r)) : a[src]
     for (int round = 0; round < 24; round++) {
-        uint64_t c[5], d[5], b[25];
-        for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
-        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
-        for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
-        // rho + pi: B[y, 2x+3y] = rot(A[x,y])
-        for (int x = 0; x < 5; x++)
-            for (int y = 0; y < 5; y++) {
-                int r = RHO[x + 5 * y];
-                uint64_t v = s[x + 5 * y];
-                b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? rotl64(v, r) : v;
-            }
-        for (int y = 0; y < 5; y++)
-            for (int x = 0; x < 5; x++) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
-        s[0] ^= RC[round];
+        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20], c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+        uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22], c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+        uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1),
+                 d4 = c3 ^ rotl64(c0, 1);
+        for (int y = 0; y < 25; y += 5) {
+            a[y] ^= d0;
+            a[y + 1] ^= d1;
+            a[y + 2] ^= d2;
+            a[y + 3] ^= d3;
+            a[y + 4] ^= d4;
+        }
+        uint64_t b[25];
+        // rho + pi: B[y + 5((2x+3y) mod 5)] = rot(A[x + 5y], rho[x][y])
+        BPG_RHOPI(0, 0, 0);    BPG_RHOPI(10, 1, 1);   BPG_RHOPI(20, 2, 62);  BPG_RHOPI(5, 3, 28);   BPG_RHOPI(15, 4, 27);
+        BPG_RHOPI(16, 5, 36);  BPG_RHOPI(1, 6, 44);   BPG_RHOPI(11, 7, 6);   BPG_RHOPI(21, 8, 55);  BPG_RHOPI(6, 9, 20);
+        BPG_RHOPI(7, 10, 3);   BPG_RHOPI(17, 11, 10); BPG_RHOPI(2, 12, 43);  BPG_RHOPI(12, 13, 25); BPG_RHOPI(22, 14, 39);
+        BPG_RHOPI(23, 15, 41); BPG_RHOPI(8, 16, 45);  BPG_RHOPI(18, 17, 15); BPG_RHOPI(3, 18, 21);  BPG_RHOPI(13, 19, 8);
+        BPG_RHOPI(14, 20, 18); BPG_RHOPI(24, 21, 2);  BPG_RHOPI(9, 22, 61);  BPG_RHOPI(19, 23, 56); BPG_RHOPI(4, 24, 14);
+        for (int y = 0; y < 25; y += 5) {
+            a[y] = b[y] ^ (~b[y + 1] & b[y + 2]);
+            a[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]);
+            a[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]);
+            a[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]);
+            a[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]);
+        }
+        a[0] ^= RC[round];
     }
+#undef BPG_RHOPI
+    for (int i = 0; i < 25; i++) s[i] = a[i];
 }
 
 // Keccak sponge with byte-granular absorb / squeeze (SHAKE256: rate 136, pad 0x1f; SHA3-512: rate 72, pad 0x06)

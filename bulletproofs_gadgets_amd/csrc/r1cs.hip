@@ -106,6 +106,16 @@ __global__ void __launch_bounds__(256) k_flatten(const uint32_t *__restrict__ sl
     st_sc(W + s, acc);
 }
 
+// per-block partial sums of  sum_t zpow[q_t] * coeffs[c_t]  (the constant terms -> wc)
+__global__ void __launch_bounds__(256) k_dot_zpow(const uint32_t *__restrict__ t_coeff, const uint32_t *__restrict__ t_q,
+                                                  const sc *__restrict__ coeffs, const sc *__restrict__ zpow, uint32_t nterms,
+                                                  sc *__restrict__ partial) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    sc v[1] = {sc_zero()};
+    if (t < nterms) v[0] = mul_(ld_sc(zpow + t_q[t]), ld_sc(coeffs + t_coeff[t]));
+    block_sum<1>(v, partial);
+}
+
 // l(X), r(X) coefficient vectors and the per-block partial sums of t1..t6
 //   l1 = a_L + y^-i wR   l2 = a_O   l3 = s_L      r0 = wO - y^i   r1 = y^i a_R + wL   r3 = y^i s_R
 __global__ void __launch_bounds__(256) k_poly(uint32_t n, const sc *__restrict__ aL, const sc *__restrict__ aR,
@@ -464,13 +474,16 @@ static double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// slots by variable: counting sort of the constraint terms (host, O(terms))
+// slots by variable: counting sort of the constraint terms (host, O(terms)).
+// Constant (Variable::One) terms are numerous (every public coordinate is one) and all
+// land in the single scalar wc, so they are kept apart and summed by a parallel
+// dot-product kernel instead of by one thread.
 struct FlatPlan {
-    std::vector<uint32_t> slot_off, t_coeff, t_q;
+    std::vector<uint32_t> slot_off, t_coeff, t_q, one_coeff, one_q;
     uint32_t nslots = 0, neg_from = 0;
 };
 static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc, FlatPlan &fp) {
-    fp.nslots = 3 * n + m + (want_wc ? 1 : 0);
+    fp.nslots = 3 * n + m;
     fp.neg_from = 3 * n;
     fp.slot_off.assign(fp.nslots + 1, 0);
     const size_t nt = cs.term_var.size();
@@ -481,7 +494,7 @@ static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, b
             case VAR_RIGHT: return (int64_t)n + idx;
             case VAR_OUTPUT: return 2 * (int64_t)n + idx;
             case VAR_COMMITTED: return 3 * (int64_t)n + idx;
-            default: return want_wc ? 3 * (int64_t)n + m : -1;
+            default: return -1;
         }
     };
     for (size_t t = 0; t < nt; t++) {
@@ -494,15 +507,24 @@ static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, b
     fp.t_q.resize(fp.slot_off[fp.nslots]);
     for (size_t t = 0; t < nt; t++) {
         int64_t s = slot_of(cs.term_var[t]);
-        if (s < 0) continue;
+        if (s < 0) {
+            if (want_wc) {
+                fp.one_coeff.push_back(cs.term_coeff[t]);
+                fp.one_q.push_back(cs.term_q[t]);
+            }
+            continue;
+        }
         uint32_t pos = cur[s]++;
         fp.t_coeff[pos] = cs.term_coeff[t];
         fp.t_q[pos] = cs.term_q[t];
     }
 }
 
-// runs k_zpow + k_flatten; W (device) receives nslots scalars
-static int gpu_flatten(bpg_ctx *ctx, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W) {
+// runs k_zpow + k_flatten (+ k_dot_zpow for the constant terms); W (device) receives
+// nslots scalars; *d_one / *n_one receive the per-block partial sums of sum z^(q+1) c over
+// the constant terms (the caller adds them up and negates to get wc).
+static int gpu_flatten(bpg_ctx *ctx, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W,
+                       sc **d_one = nullptr, size_t *n_one = nullptr) {
     hipStream_t s = ctx->stream;
     const uint32_t Q = cs.num_constraints;
     sc ztbl[32];
@@ -522,13 +544,25 @@ static int gpu_flatten(bpg_ctx *ctx, Arena &ar, const ConstraintStore &cs, const
     if (fp.nslots)
         hipLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, d_off, d_tc, d_tq, d_coeffs, d_zpow, d_W,
                            fp.nslots, fp.neg_from);
+    if (d_one) {
+        const size_t no = fp.one_coeff.size(), nb = grid256(no ? no : 1);
+        *n_one = no ? nb : 0;
+        *d_one = ar.take<sc>(nb);
+        if (no) {
+            uint32_t *d_oc = ar.take<uint32_t>(no), *d_oq = ar.take<uint32_t>(no);
+            BPG_CHECK_HIP(hipMemcpyAsync(d_oc, fp.one_coeff.data(), no * 4, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(d_oq, fp.one_q.data(), no * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_dot_zpow, dim3((unsigned)nb), dim3(256), 0, s, d_oc, d_oq, d_coeffs, d_zpow, (uint32_t)no, *d_one);
+        }
+    }
     BPG_CHECK_HIP(hipGetLastError());
     return BPG_OK;
 }
 
 static size_t flatten_bytes(const ConstraintStore &cs, const FlatPlan &fp) {
     return pad256(32 * 32) + pad256((cs.num_constraints + 1) * 32) + pad256((cs.coeffs.size() + 1) * 32) +
-           pad256((fp.nslots + 1) * 4) + 2 * pad256((fp.t_coeff.size() + 1) * 4);
+           pad256((fp.nslots + 1) * 4) + 2 * pad256((fp.t_coeff.size() + 1) * 4) + 2 * pad256((fp.one_coeff.size() + 1) * 4) +
+           pad256((fp.one_coeff.size() / 256 + 2) * 32);
 }
 
 // =================================================================== generators
@@ -968,7 +1002,9 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     Arena ar(ctx);
     if ((rc = ar.reserve(need))) return rc;
     sc *d_W = ar.take<sc>(fp.nslots + 1);
-    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W))) return rc;
+    sc *d_one = nullptr;
+    size_t n_one = 0;
+    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W, &d_one, &n_one))) return rc;
     sc yinvtbl[32];
     pow2_table(yinvtbl, y.invert().v);
     sc *d_yinvtbl = ar.take<sc>(32), *d_uk = ar.take<sc>(lg + 1), *d_ukinv = ar.take<sc>(lg + 1);
@@ -981,13 +1017,14 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     hipLaunchKernelGGL(k_verify_scalars, dim3((unsigned)nblk), dim3(256), 0, s, A, d_W, d_yinvtbl, d_uk, d_ukinv, d_sc, d_sc + np,
                        d_part);
     BPG_CHECK_HIP(hipGetLastError());
-    std::vector<sc> h_part(nblk), wV(m + 1);
+    std::vector<sc> h_part(nblk), wV(m + 1), h_one(n_one + 1);
     BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk * 32, hipMemcpyDeviceToHost, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, (m + 1) * 32, hipMemcpyDeviceToHost, s));   // wV | wc
+    if (m) BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
+    if (n_one) BPG_CHECK_HIP(hipMemcpyAsync(h_one.data(), d_one, n_one * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    Scalar delta(0);
+    Scalar delta(0), wc(0);
     for (size_t b = 0; b < nblk; b++) delta += Scalar(h_part[b]);
-    const Scalar wc(wV[m]);
+    for (size_t b = 0; b < n_one; b++) wc -= Scalar(h_one[b]);
     const Scalar xx = x * x, rxx = r * xx, xxx = x * xx, ab = P.a * P.b;
     std::vector<sc> tail;
     tail.reserve(2 + ndyn);
