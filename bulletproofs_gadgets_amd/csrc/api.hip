@@ -94,17 +94,49 @@ __global__ void __launch_bounds__(256) k_compress(const aniels_rec *__restrict__
     o[1] = make_uint4(b[4], b[5], b[6], b[7]);
 }
 
+static std::atomic<uint64_t> g_next_ctx_id{1};
+
+bpg_lane *lane_of(bpg_ctx *ctx) {
+    struct Slot {
+        uint64_t id;
+        bpg_lane *lane;
+    };
+    static thread_local std::vector<Slot> cache;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    for (auto &s : cache)
+        if (s.id == ctx->id) return s.lane;
+    bpg_lane *lane = new bpg_lane();
+    lane->ctx = ctx;
+    hipError_t e = hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_last_error("hipStreamCreateWithFlags(lane)", e);
+        delete lane;
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->lanes.push_back(lane);
+    }
+    cache.push_back({ctx->id, lane});
+    return lane;
+}
+
+#define BPG_LANE(ctx)                    \
+    bpg_lane *lane = bpg::lane_of(ctx);  \
+    if (!lane) return BPG_EDEVICE
+
 // Fill table entries [dst, dst + n) from host bytes (used by the generator table and by
 // the verifier's per-proof points).  uniform: 64 B each (from_uniform_bytes);
 // compressed: 32 B each (decompress); *n_bad receives the number of invalid encodings.
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n) {
     if (!n) return BPG_OK;
+    BPG_LANE(ctx);
     uint8_t *d_in = nullptr;
     BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host64, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, dst, n);
+    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host64, n * 64, hipMemcpyHostToDevice, lane->stream));
+    hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
     (void)hipFree(d_in);
     return BPG_OK;
 }
@@ -112,16 +144,17 @@ int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, si
 int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad) {
     *n_bad = 0;
     if (!n) return BPG_OK;
+    BPG_LANE(ctx);
     uint8_t *d_in = nullptr;
     BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
     uint32_t *d_flag = nullptr;
     BPG_CHECK_HIP(hipMalloc((void **)&d_flag, 4));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, dst, n, d_flag);
+    BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, lane->stream));
+    BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, lane->stream));
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n, d_flag);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(n_bad, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    BPG_CHECK_HIP(hipMemcpyAsync(n_bad, d_flag, 4, hipMemcpyDeviceToHost, lane->stream));
+    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
     (void)hipFree(d_in);
     (void)hipFree(d_flag);
     return BPG_OK;
@@ -148,7 +181,7 @@ int bpg_init(int device_id, bpg_ctx **out) {
     BPG_CHECK_HIP(hipSetDevice(device_id));
     bpg_ctx *ctx = new bpg_ctx();
     ctx->device = device_id;
-    BPG_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->id = g_next_ctx_id.fetch_add(1);
     if (const char *s = getenv("BPG_MSM_C")) ctx->tune.c = atoi(s);
     if (const char *s = getenv("BPG_MSM_TILE")) ctx->tune.tile = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);
@@ -160,10 +193,15 @@ int bpg_init(int device_id, bpg_ctx **out) {
 void bpg_shutdown(bpg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto *j : ctx->jobs) msm_job_destroy(j);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->ws) (void)hipFree(ctx->ws);
-    (void)hipStreamDestroy(ctx->stream);
+    // no call may be in flight on any thread; lanes of threads that have exited are freed here too
+    for (auto *lane : ctx->lanes) {
+        for (auto *j : lane->jobs) msm_job_destroy(j);
+        (void)hipStreamSynchronize(lane->stream);
+        if (lane->ws) (void)hipFree(lane->ws);
+        if (lane->d_dyn) (void)hipFree(lane->d_dyn);
+        (void)hipStreamDestroy(lane->stream);
+        delete lane;
+    }
     delete ctx;
 }
 
@@ -212,7 +250,7 @@ static int points_alloc(bpg_ctx *ctx, size_t n, bpg_points **out) {
 
 int bpg_points_from_compressed(bpg_ctx *ctx, const uint8_t *points32, size_t n, bpg_points **out) {
     if (!ctx || !out || (n && !points32)) return BPG_EINVAL;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_LANE(ctx);
     bpg_points *p = nullptr;
     int rc = points_alloc(ctx, n, &p);
     if (rc) return rc;
@@ -222,12 +260,12 @@ int bpg_points_from_compressed(bpg_ctx *ctx, const uint8_t *points32, size_t n, 
         uint32_t bad = 0;
         BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
         BPG_CHECK_HIP(hipMalloc((void **)&d_bad, 4));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_in, points32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-        BPG_CHECK_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, p->d_table, n, d_bad);
+        BPG_CHECK_HIP(hipMemcpyAsync(d_in, points32, n * 32, hipMemcpyHostToDevice, lane->stream));
+        BPG_CHECK_HIP(hipMemsetAsync(d_bad, 0, 4, lane->stream));
+        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, p->d_table, n, d_bad);
         BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        BPG_CHECK_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, lane->stream));
+        BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
         (void)hipFree(d_in);
         (void)hipFree(d_bad);
         if (bad) {
@@ -242,17 +280,17 @@ int bpg_points_from_compressed(bpg_ctx *ctx, const uint8_t *points32, size_t n, 
 
 int bpg_points_from_uniform(bpg_ctx *ctx, const uint8_t *uniform64, size_t n, bpg_points **out) {
     if (!ctx || !out || (n && !uniform64)) return BPG_EINVAL;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_LANE(ctx);
     bpg_points *p = nullptr;
     int rc = points_alloc(ctx, n, &p);
     if (rc) return rc;
     if (n) {
         uint8_t *d_in = nullptr;
         BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_in, uniform64, n * 64, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, p->d_table, n);
+        BPG_CHECK_HIP(hipMemcpyAsync(d_in, uniform64, n * 64, hipMemcpyHostToDevice, lane->stream));
+        hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, p->d_table, n);
         BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
         (void)hipFree(d_in);
     }
     *out = p;
@@ -262,13 +300,13 @@ int bpg_points_from_uniform(bpg_ctx *ctx, const uint8_t *uniform64, size_t n, bp
 int bpg_points_compress(bpg_ctx *ctx, const bpg_points *pts, size_t start, size_t n, uint8_t *out32) {
     if (!ctx || !pts || (n && !out32) || start + n > pts->n) return BPG_EINVAL;
     if (!n) return BPG_OK;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_LANE(ctx);
     uint8_t *d_out = nullptr;
     BPG_CHECK_HIP(hipMalloc((void **)&d_out, n * 32));
-    hipLaunchKernelGGL(k_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pts->d_table + start, d_out, n);
+    hipLaunchKernelGGL(k_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, pts->d_table + start, d_out, n);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(out32, d_out, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    BPG_CHECK_HIP(hipMemcpyAsync(out32, d_out, n * 32, hipMemcpyDeviceToHost, lane->stream));
+    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
     (void)hipFree(d_out);
     return BPG_OK;
 }
@@ -284,15 +322,21 @@ void bpg_points_free(bpg_points *pts) {
 int bpg_msm_submit_segments(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len,
                             size_t n_segments, const void *d_scalars, size_t n_targets, bpg_msm_job **job) {
     if (!seg_start || !seg_len || n_segments < 1 || n_segments > 4 || n_targets < 1 || n_targets > 65535) return BPG_EINVAL;
+    if (!pts) return BPG_EINVAL;
     size_t n = 0;
-    for (size_t k = 0; k < n_segments; k++) n += seg_len[k];
-    return msm_submit(ctx, pts, seg_start, seg_len, (int)n_segments, d_scalars, n, (int)n_targets, false, job);
+    msm_seg segs[4];
+    for (size_t k = 0; k < n_segments; k++) {
+        if (seg_start[k] > pts->n || seg_len[k] > pts->n - seg_start[k]) return BPG_EINVAL;
+        segs[k] = msm_seg{pts->d_table + seg_start[k], seg_len[k]};
+        n += seg_len[k];
+    }
+    return msm_submit(ctx, segs, (int)n_segments, d_scalars, n, (int)n_targets, false, job);
 }
 
 int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, size_t n, size_t n_targets, bpg_msm_job **job) {
-    if (n_targets < 1 || n_targets > 65535) return BPG_EINVAL;
-    size_t start = 0, len = n;
-    return msm_submit(ctx, pts, &start, &len, 1, d_scalars, n, (int)n_targets, false, job);
+    if (!pts || n > pts->n || n_targets < 1 || n_targets > 65535) return BPG_EINVAL;
+    msm_seg seg{pts->d_table, n};
+    return msm_submit(ctx, &seg, 1, d_scalars, n, (int)n_targets, false, job);
 }
 
 int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32) { return msm_wait(job, out32, false); }
@@ -303,10 +347,10 @@ int bpg_msm_combine_partials(const uint8_t *partials128, size_t k, uint8_t out32
 }
 
 int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_t n, uint8_t out32[32]) {
-    if (!ctx || !pts || !out32 || (n && !scalars32)) return BPG_EINVAL;
-    size_t start = 0, len = n;
+    if (!ctx || !pts || !out32 || (n && !scalars32) || n > pts->n) return BPG_EINVAL;
+    msm_seg seg{pts->d_table, n};
     bpg_msm_job *job = nullptr;
-    int rc = msm_submit(ctx, pts, &start, &len, 1, scalars32, n, 1, true, &job);
+    int rc = msm_submit(ctx, &seg, 1, scalars32, n, 1, true, &job);
     if (rc) {
         if (job) job->busy = false;
         return rc;
@@ -326,8 +370,9 @@ int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int
 
 int bpg_msm_last_kernel_us(bpg_ctx *ctx, float *accumulate_us, float *total_device_us) {
     if (!ctx) return BPG_EINVAL;
-    if (accumulate_us) *accumulate_us = ctx->last_acc_us;
-    if (total_device_us) *total_device_us = ctx->last_total_us;
+    BPG_LANE(ctx);   // the calling thread's most recent bpg_msm_wait
+    if (accumulate_us) *accumulate_us = lane->last_acc_us;
+    if (total_device_us) *total_device_us = lane->last_total_us;
     return BPG_OK;
 }
 

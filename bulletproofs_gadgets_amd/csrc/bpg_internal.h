@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "../../include/bpg.h"
@@ -75,9 +77,11 @@ struct bpg_points {
     size_t n;
 };
 
+struct bpg_lane;
+
 // Device workspace + stream of one in-flight MSM.
 struct bpg_msm_job {
-    bpg_ctx *ctx = nullptr;
+    bpg_lane *lane = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start, acc begin, acc end, end
     bpg::msm_plan plan{};
@@ -89,23 +93,46 @@ struct bpg_msm_job {
     bpg::ge_rec *d_out = nullptr;     size_t cap_out = 0;
     bpg::ge_rec *h_out = nullptr;     size_t cap_hout = 0;      // pinned host
     void *d_stage = nullptr;          size_t cap_stage = 0;     // scalars staged from the host
-    bool busy = false;
+    std::atomic<bool> busy{false};
 };
 
-struct bpg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;     // setup / codec stream
-    std::vector<bpg_msm_job *> jobs;
-    bpg::msm_tuning tune;
+// Everything mutable that a call needs on the device.  One lane per host thread that
+// has called into a context (created on that thread's first call), so N host threads
+// drive N proofs on N streams against shared, immutable generator / point tables
+// ("one proof = one thread").
+struct bpg_lane {
+    bpg_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;     // setup / codec / scalar-vector kernel stream
+    std::vector<bpg_msm_job *> jobs;  // MSM job pool (each job has its own stream)
     float last_acc_us = 0.f, last_total_us = 0.f;
     // bump arena for the R1CS scalar-vector kernels (grown on demand, reused across proofs)
     void *ws = nullptr;
     size_t ws_cap = 0;
+    // per-proof points of a verification (commitments, proof points), decoded to affine Niels
+    bpg::aniels_rec *d_dyn = nullptr;
+    size_t dyn_cap = 0;
+};
+
+struct bpg_ctx {
+    int device = 0;
+    uint64_t id = 0;                  // process-unique; keys the per-thread lane cache
+    bpg::msm_tuning tune;
+    std::mutex mu;                    // guards lanes
+    std::vector<bpg_lane *> lanes;
 };
 
 namespace bpg {
-int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
-               const void *scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job);
+// the calling thread's lane of ctx (created on first use, device made current); nullptr on HIP failure
+bpg_lane *lane_of(bpg_ctx *ctx);
+
+// One run of consecutive table records that an MSM reads; up to 4 per MSM, possibly from
+// different tables (generator table + a lane's per-proof points).
+struct msm_seg {
+    const aniels_rec *base;
+    size_t len;
+};
+int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *scalars, size_t n, int T, bool scalars_on_host,
+               bpg_msm_job **out_job);
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n);
 int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);

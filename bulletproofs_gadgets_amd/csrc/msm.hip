@@ -294,16 +294,16 @@ __global__ void __launch_bounds__(512) k_scatter(const int16_t *__restrict__ dig
 }
 
 struct seg_map {
-    uint32_t len[4];     // cumulative ends of the segments in scalar-index space
-    uint32_t start[4];   // table index of each segment's first point
+    uint32_t len[4];             // cumulative ends of the segments in scalar-index space
+    const aniels_rec *base[4];   // record of scalar index i in segment k is base[k][i]  (base pre-shifted by -len[k-1])
 };
 
-__device__ __forceinline__ uint32_t map_index(const seg_map &m, uint32_t i) {
-    uint32_t r = m.start[0] + i;
-    r = i >= m.len[0] ? m.start[1] + (i - m.len[0]) : r;
-    r = i >= m.len[1] ? m.start[2] + (i - m.len[1]) : r;
-    r = i >= m.len[2] ? m.start[3] + (i - m.len[2]) : r;
-    return r;
+__device__ __forceinline__ const aniels_rec *map_record(const seg_map &m, uint32_t i) {
+    const aniels_rec *b = m.base[0];
+    b = i >= m.len[0] ? m.base[1] : b;
+    b = i >= m.len[1] ? m.base[2] : b;
+    b = i >= m.len[2] ? m.base[3] : b;
+    return b + i;
 }
 
 // One scanned level: offsets = local[g] + base[g >> 10]; base[nblk] = total.
@@ -334,7 +334,7 @@ __device__ __forceinline__ uint32_t find_bucket(const level_ref &lv, uint32_t t,
 
 // THE hot kernel.  Thread t owns segment `rank` (S0 entries) of bucket g and sums
 // it with 7M mixed additions.  Integer-VALU bound (v_mad_u64_u32 chains).
-__global__ void __launch_bounds__(256) k_accumulate(const aniels_rec *__restrict__ table, const uint32_t *__restrict__ entries,
+__global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ counts, level_ref ent, level_ref lv0,
                                                     ge_rec *__restrict__ parts, uint32_t nblk, uint32_t ne, int ls0,
                                                     seg_map map) {
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const aniels_rec *__restrict
     for (uint32_t e = off + lo; e < off + hi; e++) {
         uint32_t en = entries[e];
         ge_aniels q;
-        load_aniels(q, table + map_index(map, en & 0x7fffffffu));
+        load_aniels(q, map_record(map, en & 0x7fffffffu));
         ge_madd(acc, acc, q, (en >> 31) != 0);
     }
     store_ge(parts + t, acc);
@@ -510,18 +510,18 @@ static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *d
     }
 }
 
-static bpg_msm_job *acquire_job(bpg_ctx *ctx) {
-    for (auto *j : ctx->jobs)
-        if (!j->busy) return j;
+static bpg_msm_job *acquire_job(bpg_lane *lane) {
+    for (auto *j : lane->jobs)
+        if (!j->busy.load(std::memory_order_acquire)) return j;
     auto *j = new bpg_msm_job();
-    j->ctx = ctx;
+    j->lane = lane;
     if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) {
         delete j;
         return nullptr;
     }
     for (auto &e : j->ev)
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    ctx->jobs.push_back(j);
+    lane->jobs.push_back(j);
     return j;
 }
 
@@ -542,27 +542,28 @@ void msm_job_destroy(bpg_msm_job *j) {
     delete j;
 }
 
-int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, const size_t *seg_len, int nseg,
-               const void *d_scalars, size_t n, int T, bool scalars_on_host, bpg_msm_job **out_job) {
-    if (!ctx || !pts || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
+int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalars, size_t n, int T, bool scalars_on_host,
+               bpg_msm_job **out_job) {
+    if (!ctx || !segs || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
     if (n >= ((size_t)1 << 28)) return BPG_EINVAL;
     seg_map map{};
     {
         size_t acc = 0;
         for (int k = 0; k < 4; k++) {
             if (k < nseg) {
-                if (seg_start[k] + seg_len[k] > pts->n) return BPG_EINVAL;
-                acc += seg_len[k];
-                map.start[k] = (uint32_t)seg_start[k];
+                if (segs[k].len && !segs[k].base) return BPG_EINVAL;
+                map.base[k] = segs[k].base - acc;
+                acc += segs[k].len;
             } else {
-                map.start[k] = 0;
+                map.base[k] = nullptr;
             }
             map.len[k] = k < nseg ? (uint32_t)acc : 0xffffffffu;
         }
         if (acc != n) return BPG_EINVAL;
     }
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
-    bpg_msm_job *j = acquire_job(ctx);
+    bpg_lane *lane = lane_of(ctx);
+    if (!lane) return BPG_EDEVICE;
+    bpg_msm_job *j = acquire_job(lane);
     if (!j) return BPG_EDEVICE;
     msm_plan pl = make_plan(n, T, ctx->tune);
     j->plan = pl;
@@ -639,7 +640,7 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
         L.parts[r] = j->d_partials + part_off[r];
     }
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, pts->d_table, j->d_entries,
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries,
                        counts, ent, L.lv[0], j->d_partials + part_off[0], (uint32_t)nblk, (uint32_t)NE, pl.ls0, map);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
     for (int r = 1; r < nlevels; r++) {
@@ -665,10 +666,11 @@ int msm_submit(bpg_ctx *ctx, const bpg_points *pts, const size_t *seg_start, con
 int msm_wait(bpg_msm_job *j, uint8_t *out, bool partial) {
     if (!j || !j->busy || !out) return BPG_EINVAL;
     BPG_CHECK_HIP(hipEventSynchronize(j->ev[3]));
-    (void)hipEventElapsedTime(&j->ctx->last_acc_us, j->ev[1], j->ev[2]);
-    (void)hipEventElapsedTime(&j->ctx->last_total_us, j->ev[0], j->ev[3]);
-    j->ctx->last_acc_us *= 1000.f;
-    j->ctx->last_total_us *= 1000.f;
+    float acc_ms = 0.f, tot_ms = 0.f;
+    (void)hipEventElapsedTime(&acc_ms, j->ev[1], j->ev[2]);
+    (void)hipEventElapsedTime(&tot_ms, j->ev[0], j->ev[3]);
+    j->lane->last_acc_us = acc_ms * 1000.f;
+    j->lane->last_total_us = tot_ms * 1000.f;
     const msm_plan &pl = j->plan;
     for (int t = 0; t < pl.T; t++) {
         ge acc;
@@ -701,7 +703,7 @@ int msm_wait(bpg_msm_job *j, uint8_t *out, bool partial) {
             ristretto_encode(out + 32 * t, acc);
         }
     }
-    j->busy = false;
+    j->busy.store(false, std::memory_order_release);
     return BPG_OK;
 }
 

@@ -112,18 +112,19 @@ class ConstraintSystem {
 
 // ---- generators ----------------------------------------------------------------
 // PedersenGens::default() and BulletproofGens::new(cap, 1), resident on one GPU:
-// table = [ G_0..G_{cap-1} | H_0..H_{cap-1} | B | B_blinding | scratch for proof points ].
+// table = [ G_0..G_{cap-1} | H_0..H_{cap-1} | B | B_blinding ].  Immutable after creation:
+// any number of host threads may prove / verify against one Gens concurrently.
 struct Gens {
     bpg_ctx *ctx = nullptr;
     bpg_points *table = nullptr;
-    size_t capacity = 0, dyn_capacity = 0;
+    void *d_comb = nullptr;           // radix-16 comb tables of B and B_blinding (Pedersen kernel)
+    size_t capacity = 0;
     size_t off_G() const { return 0; }
     size_t off_H() const { return capacity; }
     size_t off_B() const { return 2 * capacity; }
     size_t off_Bb() const { return 2 * capacity + 1; }
-    size_t off_dyn() const { return 2 * capacity + 2; }
 };
-int gens_create(bpg_ctx *ctx, size_t capacity, size_t dyn_capacity, Gens **out);
+int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out);
 void gens_destroy(Gens *g);
 
 // ---- proof ----------------------------------------------------------------------

@@ -439,23 +439,23 @@ bool R1CSProof::from_bytes(const uint8_t *d, size_t len, R1CSProof &o) {
 // =================================================================== host: device arena + helpers
 
 struct Arena {
-    bpg_ctx *ctx;
+    bpg_lane *lane;
     size_t used = 0;
-    explicit Arena(bpg_ctx *c) : ctx(c) {}
+    explicit Arena(bpg_lane *l) : lane(l) {}
     int reserve(size_t bytes) {
-        if (bytes <= ctx->ws_cap) return BPG_OK;
-        if (ctx->ws) (void)hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_cap = 0;
+        if (bytes <= lane->ws_cap) return BPG_OK;
+        if (lane->ws) (void)hipFree(lane->ws);
+        lane->ws = nullptr;
+        lane->ws_cap = 0;
         size_t want = bytes + bytes / 4 + (1 << 20);
-        BPG_CHECK_HIP(hipMalloc(&ctx->ws, want));
-        ctx->ws_cap = want;
+        BPG_CHECK_HIP(hipMalloc(&lane->ws, want));
+        lane->ws_cap = want;
         return BPG_OK;
     }
     template <typename T>
     T *take(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-        T *p = (T *)((uint8_t *)ctx->ws + used);
+        T *p = (T *)((uint8_t *)lane->ws + used);
         used += bytes;
         return p;
     }
@@ -523,9 +523,9 @@ static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, b
 // runs k_zpow + k_flatten (+ k_dot_zpow for the constant terms); W (device) receives
 // nslots scalars; *d_one / *n_one receive the per-block partial sums of sum z^(q+1) c over
 // the constant terms (the caller adds them up and negates to get wc).
-static int gpu_flatten(bpg_ctx *ctx, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W,
+static int gpu_flatten(bpg_lane *lane, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W,
                        sc **d_one = nullptr, size_t *n_one = nullptr) {
-    hipStream_t s = ctx->stream;
+    hipStream_t s = lane->stream;
     const uint32_t Q = cs.num_constraints;
     sc ztbl[32];
     pow2_table(ztbl, z);
@@ -570,18 +570,17 @@ static size_t flatten_bytes(const ConstraintStore &cs, const FlatPlan &fp) {
 struct GensExtra {
     aniels_rec *d_comb = nullptr;     // 2 x 64 x 8 comb table for B, B~
 };
-static std::unordered_map<Gens *, GensExtra> g_extra;
 
-int gens_create(bpg_ctx *ctx, size_t capacity, size_t dyn_capacity, Gens **out) {
+int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out) {
     if (!ctx || !out || capacity == 0 || capacity > ((size_t)1 << 26)) return BPG_EINVAL;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    bpg_lane *lane = lane_of(ctx);
+    if (!lane) return BPG_EDEVICE;
     Gens *g = new Gens();
     g->ctx = ctx;
     g->capacity = capacity;
-    g->dyn_capacity = dyn_capacity;
     bpg_points *tbl = new bpg_points();
     tbl->ctx = ctx;
-    tbl->n = 2 * capacity + 2 + dyn_capacity;
+    tbl->n = 2 * capacity + 2;
     tbl->d_table = nullptr;
     hipError_t e = hipMalloc((void **)&tbl->d_table, tbl->n * sizeof(aniels_rec));
     if (e != hipSuccess) {
@@ -615,21 +614,17 @@ int gens_create(bpg_ctx *ctx, size_t capacity, size_t dyn_capacity, Gens **out) 
     if ((rc = table_write_uniform(ctx, tbl->d_table + g->off_Bb(), h, 1))) return rc;
     GensExtra ex;
     BPG_CHECK_HIP(hipMalloc((void **)&ex.d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
-    hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, ctx->stream, tbl->d_table + g->off_B(), ex.d_comb);
+    hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), ex.d_comb);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    g_extra[g] = ex;
+    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    g->d_comb = ex.d_comb;
     *out = g;
     return BPG_OK;
 }
 
 void gens_destroy(Gens *g) {
     if (!g) return;
-    auto it = g_extra.find(g);
-    if (it != g_extra.end()) {
-        (void)hipFree(it->second.d_comb);
-        g_extra.erase(it);
-    }
+    if (g->d_comb) (void)hipFree(g->d_comb);
     if (g->table) {
         (void)hipFree(g->table->d_table);
         delete g->table;
@@ -640,14 +635,15 @@ void gens_destroy(Gens *g) {
 // m Pedersen commitments (K3); scalars = [m][2] host; out32 host
 static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     if (!m) return BPG_OK;
-    bpg_ctx *ctx = g->ctx;
-    hipStream_t s = ctx->stream;
+    bpg_lane *lane = lane_of(g->ctx);
+    if (!lane) return BPG_EDEVICE;
+    hipStream_t s = lane->stream;
     sc *d_s = nullptr;
     uint8_t *d_o = nullptr;
     BPG_CHECK_HIP(hipMalloc((void **)&d_s, m * 64));
     BPG_CHECK_HIP(hipMalloc((void **)&d_o, m * 32));
     BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, g_extra[g].d_comb, d_s, (uint32_t)m, d_o);
+    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
@@ -728,8 +724,10 @@ static inline size_t next_pow2(size_t n) {
 int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     const double t_start = now_ms();
     bpg_ctx *ctx = gens_->ctx;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    bpg_lane *lane = lane_of(ctx);
+    if (!lane) return BPG_EDEVICE;
+    hipStream_t s = lane->stream;
+    const aniels_rec *tbl = gens_->table->d_table;
     const size_t n = a_L_.size(), m = v_.size();
     const size_t np = next_pow2(n ? n : 1);
     if (gens_->capacity < np) return BPG_EGENS;
@@ -762,7 +760,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     size_t need = pad256(3 * N1 * 32) + 5 * pad256((n + 1) * 32) + pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) +
                   4 * pad256((n + 1) * 32) + pad256(nblk_n * 6 * 32) + 2 * pad256(32 * 32) + 4 * pad256(np * 32) +
                   pad256(2 * NR * 32) + pad256(nblk_np * 2 * 32) + (1 << 16);
-    Arena ar(ctx);
+    Arena ar(lane);
     int rc = ar.reserve(need);
     if (rc) return rc;
     sc *d_rows = ar.take<sc>(3 * N1);
@@ -785,9 +783,9 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     // ---- A_I1, A_O1, S1: one 3-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
     {
-        size_t st[3] = {gens_->off_Bb(), gens_->off_G(), gens_->off_H()}, ln[3] = {1, n, n};
+        msm_seg segs[3] = {{tbl + gens_->off_Bb(), 1}, {tbl + gens_->off_G(), n}, {tbl + gens_->off_H(), n}};
         bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, gens_->table, st, ln, 3, d_rows, N1, 3, false, &job))) return rc;
+        if ((rc = msm_submit(ctx, segs, 3, d_rows, N1, 3, false, &job))) return rc;
         uint8_t out[96];
         if ((rc = msm_wait(job, out, false))) return rc;
         memcpy(P.A_I1, out, 32);
@@ -810,7 +808,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     // ---- flatten, l/r polynomials, t coefficients
     const double t2 = now_ms();
     sc *d_W = ar.take<sc>(fp.nslots + 1);
-    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W))) return rc;
+    if ((rc = gpu_flatten(lane, ar, cs_, fp, z.v, d_W))) return rc;
     sc ytbl[32], yinvtbl[32];
     const Scalar y_inv = y.invert();
     pow2_table(ytbl, y.v);
@@ -880,9 +878,9 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
                            d_rowLR + NR + 2 * np);
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(hipStreamSynchronize(s));
-        size_t st[3] = {gens_->off_G(), gens_->off_H(), gens_->off_B()}, ln[3] = {np, np, 1};
+        msm_seg segs[3] = {{tbl + gens_->off_G(), np}, {tbl + gens_->off_H(), np}, {tbl + gens_->off_B(), 1}};
         bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, gens_->table, st, ln, 3, d_rowLR, NR, 2, false, &job))) return rc;
+        if ((rc = msm_submit(ctx, segs, 3, d_rowLR, NR, 2, false, &job))) return rc;
         uint8_t out[64];
         if ((rc = msm_wait(job, out, false))) return rc;
         memcpy(&P.L_vec[32 * k], out, 32);
@@ -933,8 +931,9 @@ ConstraintSystem::Triple Verifier::allocate_multiplier(const Scalar *, const Sca
 
 int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
     bpg_ctx *ctx = gens->ctx;
-    BPG_CHECK_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    bpg_lane *lane = lane_of(ctx);
+    if (!lane) return BPG_EDEVICE;
+    hipStream_t s = lane->stream;
     const size_t n = num_vars_, m = V_.size() / 32;
     const size_t np = next_pow2(n ? n : 1);
     size_t lg = 0;
@@ -978,9 +977,10 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     rng.finalize(ext);
     const Scalar r = rng.scalar();
 
-    // per-proof points -> scratch region of the generator table: [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T.. | L.. | R..]
+    // per-proof points -> this lane's point scratch: [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T.. | L.. | R..]
     const size_t ndyn = 6 + m + 5 + 2 * lg;
-    if (ndyn > gens->dyn_capacity) return BPG_EGENS;
+    int rc = grow((void **)&lane->d_dyn, &lane->dyn_cap, ndyn * sizeof(aniels_rec));
+    if (rc) return rc;
     std::vector<uint8_t> dyn;
     dyn.reserve(32 * ndyn);
     auto put = [&](const uint8_t *p) { dyn.insert(dyn.end(), p, p + 32); };
@@ -990,8 +990,7 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     dyn.insert(dyn.end(), P.L_vec.begin(), P.L_vec.end());
     dyn.insert(dyn.end(), P.R_vec.begin(), P.R_vec.end());
     uint32_t bad = 0;
-    int rc = table_write_compressed(ctx, gens->table->d_table + gens->off_dyn(), dyn.data(), ndyn, &bad);
-    if (rc) return rc;
+    if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
     if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
 
     FlatPlan fp;
@@ -999,12 +998,12 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     const size_t NS = 2 * np + 2 + ndyn, nblk = grid256(np);
     size_t need = pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) + pad256(32 * 32) + 2 * pad256((lg + 1) * 32) +
                   pad256(NS * 32) + pad256(nblk * 32) + (1 << 16);
-    Arena ar(ctx);
+    Arena ar(lane);
     if ((rc = ar.reserve(need))) return rc;
     sc *d_W = ar.take<sc>(fp.nslots + 1);
     sc *d_one = nullptr;
     size_t n_one = 0;
-    if ((rc = gpu_flatten(ctx, ar, cs_, fp, z.v, d_W, &d_one, &n_one))) return rc;
+    if ((rc = gpu_flatten(lane, ar, cs_, fp, z.v, d_W, &d_one, &n_one))) return rc;
     sc yinvtbl[32];
     pow2_table(yinvtbl, y.invert().v);
     sc *d_yinvtbl = ar.take<sc>(32), *d_uk = ar.take<sc>(lg + 1), *d_ukinv = ar.take<sc>(lg + 1);
@@ -1039,9 +1038,10 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     for (size_t k = 0; k < lg; k++) tail.push_back(u_inv_sq[k]);                  // R
     BPG_CHECK_HIP(hipMemcpyAsync(d_sc + 2 * np, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    size_t st[3] = {gens->off_G(), gens->off_H(), gens->off_B()}, ln[3] = {np, np, 2 + ndyn};
+    const aniels_rec *tbl = gens->table->d_table;
+    msm_seg segs[4] = {{tbl + gens->off_G(), np}, {tbl + gens->off_H(), np}, {tbl + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
     bpg_msm_job *job = nullptr;
-    if ((rc = msm_submit(ctx, gens->table, st, ln, 3, d_sc, NS, 1, false, &job))) return rc;
+    if ((rc = msm_submit(ctx, segs, 4, d_sc, NS, 1, false, &job))) return rc;
     uint8_t out[32];
     if ((rc = msm_wait(job, out, false))) return rc;
     uint8_t acc = 0;

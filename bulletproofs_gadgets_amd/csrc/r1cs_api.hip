@@ -70,10 +70,10 @@ SonnyPoint point_in(const uint8_t *xyzt128) {
 extern "C" {
 
 // ---------------------------------------------------------------- generators
-int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t max_commitments, bpg_gens **out) {
-    if (!out) return BPG_EINVAL;
+int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, bpg_gens **out) {
+    if (!out || party_capacity != 1) return BPG_EINVAL;
     Gens *g = nullptr;
-    int rc = gens_create(ctx, gens_capacity, max_commitments + 11 + 2 * 40, &g);
+    int rc = gens_create(ctx, gens_capacity, &g);
     if (rc) return rc;
     *out = new bpg_gens{g};
     return BPG_OK;
@@ -180,6 +180,13 @@ int bpg_verifier_commit(bpg_verifier *v, const uint8_t V32[32], uint64_t *var) {
     if (!v || !V32 || !var) return BPG_EINVAL;
     *var = pack_var(v->v->commit(V32));
     return BPG_OK;
+}
+int bpg_verifier_commit_batch(bpg_verifier *v, const uint8_t *V32, size_t m, uint64_t *vars) {
+    if (!v || (m && (!V32 || !vars))) return BPG_EINVAL;
+    return guarded([&] {
+        for (size_t i = 0; i < m; i++) vars[i] = pack_var(v->v->commit(V32 + 32 * i));
+        return BPG_OK;
+    });
 }
 int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, size_t proof_len, bpg_rng_fn rng, void *rng_user) {
     if (!v || !gens || !proof || !rng) return BPG_EINVAL;

@@ -105,10 +105,10 @@ def _rng_cb(data):
 class BulletproofGens:
     """BulletproofGens::new(capacity, 1) + PedersenGens::default(), resident on the context's GPU."""
 
-    def __init__(self, ctx, gens_capacity, max_commitments=4096):
+    def __init__(self, ctx, gens_capacity, party_capacity=1):
         self.ctx, self.gens_capacity = ctx, gens_capacity
         h = ctypes.c_void_p()
-        check(lib().bpg_gens_create(ctx._h, gens_capacity, max_commitments, ctypes.byref(h)))
+        check(lib().bpg_gens_create(ctx._h, gens_capacity, party_capacity, ctypes.byref(h)))
         self._h = h.value
 
     def export(self, which, start=0, n=1):
@@ -175,6 +175,15 @@ class Prover(_CS):
         check(lib().bpg_prover_commit_batch(self._h, b"".join(_sc(x) for x in values), b"".join(_sc(x) for x in blindings), m, V, vars_))
         return [V.raw[32 * i:32 * i + 32] for i in range(m)], [Variable(vars_[i]) for i in range(m)]
 
+    def commit_batch_raw(self, values32, blindings32):
+        """commit_batch over packed 32-byte little-endian scalars; returns (packed commitments,
+        ctypes array of variable codes) without per-item Python work (throughput drivers)"""
+        m = len(values32) // 32
+        V = ctypes.create_string_buffer(32 * max(m, 1))
+        vars_ = (ctypes.c_uint64 * max(m, 1))()
+        check(lib().bpg_prover_commit_batch(self._h, values32, blindings32, m, V, vars_))
+        return V, vars_
+
     def prove(self, bp_gens=None, external_rng32=bytes(32)):
         assert bp_gens is None or bp_gens is self.gens
         cb = _rng_cb(external_rng32)
@@ -214,6 +223,12 @@ class Verifier(_CS):
         var = ctypes.c_uint64()
         check(lib().bpg_verifier_commit(self._h, V32, ctypes.byref(var)))
         return Variable(var.value)
+
+    def commit_batch_raw(self, V):
+        m = len(V) // 32
+        vars_ = (ctypes.c_uint64 * max(m, 1))()
+        check(lib().bpg_verifier_commit_batch(self._h, V, m, vars_))
+        return vars_
 
     def verify(self, proof, pc_gens, bp_gens, external_rng32=bytes(32)):
         """Ok(()) -> True; Err(R1CSError::VerificationError) -> raises VerificationError"""
@@ -299,7 +314,7 @@ class SonnyEdwardsPointGadget(_PointGadget):
 
     @classmethod
     def scalar_mul(cls, point, sk, cs):
-        arr = (ctypes.c_uint64 * max(len(sk), 1))(*[v.code for v in sk])
+        arr = sk if isinstance(sk, ctypes.Array) else (ctypes.c_uint64 * max(len(sk), 1))(*[v.code for v in sk])
         return cls._new(lib().bpg_edwards_scalar_mul, cs._cs, point._h, arr, len(sk))
 
     @classmethod

@@ -134,8 +134,10 @@ typedef void (*bpg_rng_fn)(void *user, uint8_t *out, size_t n);
 
 /* BulletproofGens::new(gens_capacity, 1) + PedersenGens::default()
  * (ref: tests/edwards_point.rs:89-90,167-168,252-253,285-286,366-367; scalar.rs:69-70; sk_know_gadget.rs:94-95).
- * max_commitments bounds the number of high-level commitments a verified proof may carry. */
-int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t max_commitments, bpg_gens **out);
+ * party_capacity must be 1, the only value the reference passes (R1CS proofs use share(0)); else BPG_EINVAL.
+ * The object is immutable once created: any number of host threads may prove and verify
+ * against it at the same time, each on its own stream (one proof = one thread, as in the reference). */
+int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, bpg_gens **out);
 void bpg_gens_free(bpg_gens *gens);
 size_t bpg_gens_capacity(const bpg_gens *gens);
 /* compress generators: which = 'G' | 'H' (party-0 share), 'B' (pc_gens.B), 'b' (pc_gens.B_blinding) */
@@ -162,6 +164,8 @@ void bpg_verifier_free(bpg_verifier *v);
 bpg_cs *bpg_verifier_cs(bpg_verifier *v);
 /* Verifier::commit(V) -> Variable   ref: edwards_point.rs:283; tests/edwards_point.rs:63 */
 int bpg_verifier_commit(bpg_verifier *v, const uint8_t V32[32], uint64_t *var);
+/* m commits in order (ref: sk_know_gadget.rs:78-81 commits 256 bit commitments one by one) */
+int bpg_verifier_commit_batch(bpg_verifier *v, const uint8_t *V32, size_t m, uint64_t *vars);
 /* Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng)   ref: tests/edwards_point.rs:79,158,242,345,412; scalar.rs:63; sk_know_gadget.rs:86
  * BPG_OK | BPG_EVERIFY (R1CSError::VerificationError) | BPG_EFORMAT | BPG_EGENS */
 int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, size_t proof_len, bpg_rng_fn rng, void *rng_user);

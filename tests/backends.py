@@ -21,7 +21,7 @@ class GpuBackend:
 
     def bp_gens(self, cap):
         if cap not in self._gens:
-            self._gens[cap] = self.g.BulletproofGens(self.ctx, cap, max_commitments=4096)
+            self._gens[cap] = self.g.BulletproofGens(self.ctx, cap, 1)
         self._cur = self._gens[cap]
         return self._cur
 

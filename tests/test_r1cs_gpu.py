@@ -190,3 +190,36 @@ def test_generators_too_short(gbe, rnd):
     with pytest.raises(BpgError) as e:
         rc.double_roundtrip(gbe, p, p.double(), cap=8)
     assert e.value.code == _native.EGENS
+
+
+def test_concurrent_provers_share_generators(gbe, obe, rnd):
+    """N host threads, each driving its own proof on its own stream against one
+    shared immutable generator object; every thread's proof bytes equal the serial run's."""
+    import threading
+    gbe.bp_gens(256)
+    pts = [(sonny.random_point(rnd), sonny.random_point(rnd)) for _ in range(6)]
+    rpts = [(sonny.RistrettoPoint(a), sonny.RistrettoPoint(b)) for a, b in pts]
+
+    def work(i):
+        if i % 2:
+            a, b = rpts[i]
+            return rc.ristretto_add_roundtrip(gbe, a, b, a + b, rng=R.SeededRng(b"t%d" % i), cap=256)
+        a, b = pts[i]
+        return rc.addition_roundtrip(gbe, a, b, a + b, rng=R.SeededRng(b"t%d" % i), cap=256)
+    serial = [work(i) for i in range(6)]
+    for _ in range(2):
+        res = [None] * 6
+        errs = []
+
+        def run(i):
+            try:
+                res[i] = work(i)
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for i in range(6):
+            assert res[i][0] and serial[i][0]
+            assert res[i][1].to_bytes() == serial[i][1].to_bytes()

@@ -25,7 +25,7 @@ def main():
     n = 27 * nbits + 4
     cap = 1 << (n - 1).bit_length()
     t0 = time.perf_counter()
-    gens = g.BulletproofGens(ctx, cap, max_commitments=nbits + 16)
+    gens = g.BulletproofGens(ctx, cap, 1)
     ctx.synchronize()
     print(json.dumps({"gens_capacity": cap, "gens_create_s": round(time.perf_counter() - t0, 3)}), flush=True)
     for r in range(reps):
