@@ -59,6 +59,92 @@ def cpu_baseline(ctx, pts, scalars, sample_n):
     return sample_n / dt, got == want, dt
 
 
+PROOF_BITS = 2427        # 27 * 2427 + 4 = 65 533 multipliers -> n+ = 2^16
+
+
+def proof_statement_bytes(nbits):
+    """cfg3 statement and per-proof randomness as packed bytes (no per-proof Python loops)"""
+    import hashlib
+    from bulletproofs_gadgets_amd import synth
+    base, bits, expected = synth.scalar_mul_statement(nbits)
+    vals = b"".join(int(b).to_bytes(32, "little") for b in bits)
+
+    def randomness(tag):
+        raw = hashlib.shake_256(synth.SEED + b"rng/" + tag).digest(31 * nbits + 64)
+        bl = b"".join(raw[31 * i:31 * i + 31] + b"\0" for i in range(nbits))    # blindings < 2^248 < l
+        return bl, raw[-64:-32], raw[-32:]
+    return base, bits, expected, vals, randomness
+
+
+def proof_bench(ctx, rank, threads, per_thread, nbits=PROOF_BITS):
+    """R1CS proofs at 2^16 multipliers on this rank's GPU: `threads` host threads, one proof per
+    thread at a time, each on its own stream against one shared generator table.  Returns
+    (proofs, seconds prove-only, seconds prove+verify, single-proof latencies in ms, a proof)."""
+    import threading
+    from bulletproofs_gadgets_amd import r1cs as g
+    base, bits, expected, vals, randomness = proof_statement_bytes(nbits)
+    n = 27 * nbits + 4
+    gens = g.BulletproofGens(ctx, 1 << (n - 1).bit_length(), 1)
+    E = g.SonnyEdwardsPointGadget
+
+    def one(tag, verify):
+        bl, ext_p, ext_v = randomness(tag)
+        p = g.Prover(gens, b"ScalarMul")
+        comms, vars_ = p.commit_batch_raw(vals, bl)
+        E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
+        proof = p.prove(gens, ext_p)
+        if verify:
+            v = g.Verifier(b"ScalarMul")
+            E.scalar_mul(E.from_point(base), v.commit_batch_raw(comms.raw), v).equal(E.from_point(expected), v)
+            assert v.verify(proof, None, gens, ext_v)
+        return proof
+
+    first = one(b"parity", True)                       # also the warm-up of the main thread's lane
+    lat = []
+    for verify in (False, True):
+        t0 = time.perf_counter()
+        one(b"lat%d" % verify, verify)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    secs = []
+    for verify in (False, True):
+        errs = []
+
+        def worker(tid, warm):
+            try:
+                for r in range(1 if warm else per_thread):
+                    one(b"%d/%d/%d" % (rank, tid, r), verify)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+        for warm in (True, False):                     # first pass: every thread's lane allocates its workspace
+            th = [threading.Thread(target=worker, args=(t, warm)) for t in range(threads)]
+            t0 = time.perf_counter()
+            [t.start() for t in th]
+            [t.join() for t in th]
+            dt = time.perf_counter() - t0
+            assert not errs, errs
+        secs.append(dt)
+    return threads * per_thread, secs[0], secs[1], lat, first
+
+
+def proof_cpu_baseline(nbits=PROOF_BITS):
+    """The oracle's prover (dalek's schedules: Straus-CT MSMs, per-element 2-term generator
+    folds) on the same statement and randomness, one host core; returns (seconds, proof bytes)."""
+    from oracle import binding, gadgets as OG, r1cs as OR
+    from bulletproofs_gadgets_amd import synth
+    orc = binding.load()
+    base, bits, expected, vals, randomness = proof_statement_bytes(nbits)
+    bl, ext_p, _ = randomness(b"parity")
+    n = 27 * nbits + 4
+    pc, bp = OR.PedersenGens(orc), OR.BulletproofGens(orc, 1 << (n - 1).bit_length(), 1)
+    t0 = time.perf_counter()
+    prover = OR.Prover(orc, pc, OR.Transcript(orc, b"ScalarMul"))
+    vars_ = [prover.commit(b, int.from_bytes(bl[32 * i:32 * i + 32], "little"))[1] for i, b in enumerate(bits)]
+    EG = OG.SonnyEdwardsPointGadget
+    EG.scalar_mul(EG.from_point(base), vars_, prover).equal(EG.from_point(expected), prover)
+    proof = prover.prove(bp, ext_p)
+    return time.perf_counter() - t0, proof.to_bytes()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +152,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--logn", type=int, default=int(os.environ.get("BPG_BENCH_LOGN", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
+    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "16")))
+    ap.add_argument("--proofs-per-thread", type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +225,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- secondary metric: R1CS proofs/s at 2^16 multipliers (independent proofs; ranks share nothing)
+    proofs = None
+    if not args.no_proofs:
+        barrier()
+        cnt, s_prove, s_pv, lat, first_proof = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread)
+        barrier()
+        if world > 1:
+            tt = torch.tensor([s_prove, s_pv], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            s_prove, s_pv = (float(x) for x in tt.tolist())
+        proofs = {"metric": "R1CS proofs/s at 2^16 multipliers", "unit": "proofs/s",
+                  "prove": world * cnt / s_prove, "prove_and_verify": world * cnt / s_pv,
+                  "multipliers": 27 * PROOF_BITS + 4, "proof_bytes": len(first_proof.to_bytes()),
+                  "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt,
+                  "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
+                  "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
+                              "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}
+
     if rank == 0:
         plan = ctx.msm_plan(n)
         acc = sum(acc_us) / len(acc_us) if acc_us else float("nan")
@@ -170,6 +277,14 @@ def main():
                                     "sample": "oracle msm_pippenger_vt (dalek vartime Pippenger, w=8) on the first 2^%d points, %.1f s"
                                               % (sample.bit_length() - 1, cpu_s),
                                     "parity_with_gpu": bool(ok)}
+        if proofs is not None:
+            if world == 1 and not args.no_cpu_baseline:
+                cpu_s, cpu_proof = proof_cpu_baseline()
+                proofs["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
+                                          "sample": "oracle prover (Straus-CT MSMs, per-element generator folds), the same "
+                                                    "statement, 1 proof, %.1f s" % cpu_s,
+                                          "proof_bytes_equal_gpu": cpu_proof == first_proof.to_bytes()}
+            line["secondary"] = proofs
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
