@@ -160,6 +160,82 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
     return BPG_OK;
 }
 
+// Fixed-base table: records [w * npts + i] = 2^(c w) P_i for w = 1 .. W-1, from window 0.
+// One thread per point walks the doubling chain, parks X | Y | Z | (running product of the Z's)
+// in the 128-byte record, then converts its W-1 points to affine Niels with ONE inversion.
+__global__ void __launch_bounds__(256) k_shift_table(aniels_rec *__restrict__ table, size_t npts, int c, int W) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    ge p;
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(table + i);
+        uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
+        fe ypx = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}}, ymx = {{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}};
+        fe two_y, two_x;
+        fe_add(two_y, ypx, ymx);
+        fe_sub(two_x, ypx, ymx);
+        // projective (2x : 2y : 2) is the same point; T = (2x)(2y)/2 = 2xy
+        p.X = two_x;
+        p.Y = two_y;
+        fe_setu32(p.Z, 2);
+        fe xy;
+        fe_mul(xy, two_x, two_y);
+        // T = XY/Z = (2x)(2y)/2: multiply by 1/2 = (p+1)/2
+        fe h = {{0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu}};
+        fe_mul(p.T, xy, h);
+    }
+    fe prod;
+    fe_set1(prod);
+    for (int w = 1; w < W; w++) {
+        for (int k = 0; k < c; k++) ge_double(p, p);
+        fe_mul(prod, prod, p.Z);
+        ge tmp = p;
+        tmp.T = prod;
+        uint4 *o = reinterpret_cast<uint4 *>(table + (size_t)w * npts + i);
+        const fe *f[4] = {&tmp.X, &tmp.Y, &tmp.Z, &tmp.T};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[2 * k] = make_uint4(f[k]->v[0], f[k]->v[1], f[k]->v[2], f[k]->v[3]);
+            o[2 * k + 1] = make_uint4(f[k]->v[4], f[k]->v[5], f[k]->v[6], f[k]->v[7]);
+        }
+    }
+    fe inv;
+    fe_invert(inv, prod);                  // 1 / (Z_1 ... Z_{W-1})
+    for (int w = W - 1; w >= 1; w--) {
+        aniels_rec *rec = table + (size_t)w * npts + i;
+        const uint4 *q = reinterpret_cast<const uint4 *>(rec);
+        fe X, Y, Z, prev;
+        uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], v5 = q[5];
+        X = {{v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}};
+        Y = {{v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w}};
+        Z = {{v4.x, v4.y, v4.z, v4.w, v5.x, v5.y, v5.z, v5.w}};
+        if (w > 1) {
+            const uint4 *qp = reinterpret_cast<const uint4 *>(table + (size_t)(w - 1) * npts + i);
+            uint4 t0 = qp[6], t1 = qp[7];
+            prev = {{t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}};
+        } else {
+            fe_set1(prev);
+        }
+        fe zinv, x, y;
+        fe_mul(zinv, inv, prev);           // 1 / Z_w
+        fe_mul(inv, inv, Z);               // 1 / (Z_1 ... Z_{w-1})
+        fe_mul(x, X, zinv);
+        fe_mul(y, Y, zinv);
+        ge_aniels n;
+        ge_affine_to_aniels(n, x, y);
+        store_aniels(rec, n);
+    }
+}
+
+int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int W) {
+    if (!npts || W < 2) return BPG_OK;
+    BPG_LANE(ctx);
+    hipLaunchKernelGGL(k_shift_table, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, lane->stream, table, npts, c, W);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    return BPG_OK;
+}
+
 }  // namespace bpg
 
 using namespace bpg;

@@ -40,7 +40,8 @@ void set_last_error_msg(const char *what);
 // Geometry of one Pippenger run.
 struct msm_plan {
     int c;            // window bits
-    int W;            // windows = 255 / c + 1
+    int W;            // digit windows = ceil(252 / c)
+    int Wb;           // bucket sets per target: W (variable-base) or 1 (fixed-base: all windows share one)
     int NB;           // buckets per window = 2^(c-1)
     int P;            // entries per accumulate thread = 2^ls0
     int ls0, ls1;     // log2 of the segment sizes: S0 entries / thread, S1 partials / merge thread
@@ -56,7 +57,10 @@ struct msm_plan {
 struct msm_tuning {
     int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
 };
-msm_plan make_plan(size_t n, int T, const msm_tuning &tune);
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c = 0);
+// fixed-base (precomputed 2^(c w) multiples) geometry for a table of `points` generators
+int fixed_base_window(size_t points);
+int fixed_base_windows(int c);
 
 int grow(void **p, size_t *cap, size_t need);
 
@@ -131,10 +135,18 @@ struct msm_seg {
     const aniels_rec *base;
     size_t len;
 };
+// Fixed-base mode: fb.c != 0.  The segments then point into window 0 of a shifted table in
+// which record (w * fb.wstride + i) holds 2^(c w) P_i, and all windows share one bucket set.
+struct msm_fixed_base {
+    int c = 0;
+    size_t wstride = 0;
+};
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *scalars, size_t n, int T, bool scalars_on_host,
-               bpg_msm_job **out_job);
+               bpg_msm_job **out_job, msm_fixed_base fb = msm_fixed_base());
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n);
 int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad);
+// table holds W * npts records with records [0, npts) filled: fills [w * npts + i] = 2^(c w) P_i
+int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int W);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);
 int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]);
 void msm_job_destroy(bpg_msm_job *job);

@@ -28,6 +28,8 @@
 
 namespace bpg {
 
+constexpr int MAX_LEVELS = 8;     // accumulate pass + up to 7 merge passes
+
 // ------------------------------------------------------------------ device helpers
 
 __device__ __forceinline__ void load_aniels(ge_aniels &q, const aniels_rec *rec) {
@@ -114,30 +116,46 @@ __device__ void lds_bit_tree(uint32_t *lds, int nslots, int nodes, int per, int 
 
 // ------------------------------------------------------------------ kernels
 
+// windows needed for a scalar below 2^251 + 2^125 (any scalar after the mod-l reduction and
+// the negation below): ceil(252 / c).  With c | 252 (c = 14, 12, 9, 7, 6, 4) every window,
+// the top one included, sees uniform digits.
+__host__ __device__ constexpr int windows_for(int c) { return (252 + c - 1) / c; }
+
 // scalar -> signed c-bit digits.  digits[(t*W + w)*n + i]
 template <int C>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, int16_t *__restrict__ digits,
                                                 size_t n, size_t total) {
-    constexpr int W = 255 / C + 1;
+    constexpr int W = windows_for(C);
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
     size_t t = gid / n, i = gid - t * n;
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + gid * 8);
     uint4 lo4 = sp[0], hi4 = sp[1];
     uint32_t v[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
-    // s > (l-1)/2  ->  use l - s and flip every digit's sign (s*P = (l-s)*(-P)).
-    // Keeps s below 2^251 so the signed recoding never carries into the top
-    // window: for uniform scalars that carry would put ~n/2 entries in one bucket.
-    // Scalars >= l (not canonical) are left as they are.
     const uint32_t HL[8] = {0x2e7ae9f6u, 0x2c09318du, 0x517bce6bu, 0x0a6f7cefu, 0u, 0u, 0u, 0x08000000u};
     const uint32_t LL[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};
+    // any 256-bit input is taken mod l (2^256 < 16 l): subtract 8l, 4l, 2l, l where they fit.
+    // The points have order l up to 4-torsion, which the Ristretto encoding ignores.
+#pragma unroll
+    for (int sh = 3; sh >= 0; sh--) {
+        uint32_t m[8], d[8], b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = (LL[k] << sh) | ((sh && k) ? (LL[k - 1] >> (32 - sh)) : 0u);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = subb32(v[k], m[k], b, b);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = b ? v[k] : d[k];
+    }
+    // s > (l-1)/2  ->  use l - s and flip every digit's sign (s*P = (l-s)*(-P)).
+    // Keeps s at or below 2^251 so the signed recoding never carries out of the top
+    // window: for uniform scalars that carry would put ~n/2 entries in one bucket.
     uint32_t bw = 0, nb = 0, ng[8], dummy;
 #pragma unroll
     for (int k = 0; k < 8; k++) dummy = subb32(HL[k], v[k], bw, bw);     // bw = (s > half)
     (void)dummy;
 #pragma unroll
-    for (int k = 0; k < 8; k++) ng[k] = subb32(LL[k], v[k], nb, nb);     // nb = (s > l)
-    const bool flip = bw && !nb;
+    for (int k = 0; k < 8; k++) ng[k] = subb32(LL[k], v[k], nb, nb);
+    const bool flip = bw != 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = flip ? ng[k] : v[k];
     int16_t *out = digits + (t * W) * n + i;
@@ -159,11 +177,12 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
 }
 
 // per (tile, window, target): LDS histogram of |digit|, flushed with coalesced atomics
+// (fixed-base mode, `shared` != 0: all windows of a target count into ONE bucket set)
 __global__ void __launch_bounds__(512) k_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ counts, size_t n,
-                                              int W, int NB, int tile) {
+                                              int W, int NB, int tile, int shared) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, t = blockIdx.z;
-    const size_t base = (size_t)t * W + w;
+    const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
     const int16_t *dg = digits + base * n;
     for (int b = threadIdx.x; b < NB; b += blockDim.x) lds[b] = 0;
     __syncthreads();
@@ -173,7 +192,7 @@ __global__ void __launch_bounds__(512) k_hist(const int16_t *__restrict__ digits
         if (d != 0) atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
     }
     __syncthreads();
-    uint32_t *gc = counts + base * NB;
+    uint32_t *gc = counts + bset * NB;
     for (int b = threadIdx.x; b < NB; b += blockDim.x) {
         uint32_t c = lds[b];
         if (c) atomicAdd(&gc[b], c);
@@ -201,39 +220,55 @@ __device__ __forceinline__ uint32_t pass_threads(uint32_t cnt, int level, int ls
     return prev > 1 ? ((prev + (1u << ls1) - 1) >> ls1) : 0u;
 }
 
-// exclusive scan, phase A: 1024 elements per block -> local offsets + block total.
-// The scanned value is pass_threads(counts[i], level).
-__global__ void __launch_bounds__(256) k_scan_a(const uint32_t *__restrict__ counts, uint32_t *__restrict__ local,
-                                                uint32_t *__restrict__ totals, size_t ne, int level, int ls0, int ls1) {
-    __shared__ uint32_t wsum[4];
-    size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = (base + k < ne) ? pass_threads(counts[base + k], level, ls0, ls1) : 0u;
-    uint32_t mine = v[0] + v[1] + v[2] + v[3];
-    uint32_t x = mine;
+// exclusive scans of pass_threads(counts[i], level) for ALL levels -1 .. nlev-2 in two
+// launches (every level depends on the counts only).  Level array idx (= level + 1) lives at
+// lvl + idx * lvl_words: local[ne] | base[nblk + 1].
+// phase A: 1024 elements per block -> offsets local to the block + block total.
+__global__ void __launch_bounds__(256) k_scan_a(const uint32_t *__restrict__ counts, uint32_t *__restrict__ lvl, size_t lvl_words,
+                                                size_t ne, int nlev, int ls0, int ls1) {
+    __shared__ uint32_t wsum[MAX_LEVELS + 1][4];
+    const size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t cnt[4];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= o) x += y;
+    for (int k = 0; k < 4; k++) cnt[k] = (base + k < ne) ? counts[base + k] : 0u;
+    uint32_t x[MAX_LEVELS + 1], mine[MAX_LEVELS + 1];
+#pragma unroll
+    for (int idx = 0; idx < MAX_LEVELS + 1; idx++) {
+        if (idx >= nlev) break;
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) m += pass_threads(cnt[k], idx - 1, ls0, ls1);
+        uint32_t v = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(v, o, 64);
+            if (lane >= o) v += y;
+        }
+        if (lane == 63) wsum[idx][wave] = v;
+        x[idx] = v;
+        mine[idx] = m;
     }
-    if (lane == 63) wsum[wave] = x;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int k = 0; k < wave; k++) wbase += wsum[k];
-    uint32_t excl = wbase + x - mine;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (base + k < ne) local[base + k] = excl;
-        excl += v[k];
+    for (int idx = 0; idx < MAX_LEVELS + 1; idx++) {
+        if (idx >= nlev) break;
+        uint32_t *local = lvl + (size_t)idx * lvl_words, *totals = local + ne;
+        uint32_t wbase = 0;
+        for (int k = 0; k < wave; k++) wbase += wsum[idx][k];
+        uint32_t excl = wbase + x[idx] - mine[idx];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (base + k < ne) local[base + k] = excl;
+            excl += pass_threads(cnt[k], idx - 1, ls0, ls1);
+        }
+        if (threadIdx.x == 255) totals[blockIdx.x] = wbase + x[idx];
     }
-    if (threadIdx.x == 255) totals[blockIdx.x] = wbase + x;
 }
 
-// exclusive scan, phase B: block totals -> block bases (single block, loops);
-// totals[nblk] receives the grand total.
-__global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ totals, size_t nblk) {
+// phase B: block totals -> block bases, one block per level; totals[nblk] = grand total.
+__global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ lvl, size_t lvl_words, size_t ne, size_t nblk) {
+    uint32_t *totals = lvl + (size_t)blockIdx.x * lvl_words + ne;
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t running;
     if (threadIdx.x == 0) running = 0;
@@ -260,13 +295,15 @@ __global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ totals, 
     if (threadIdx.x == 0) totals[nblk] = running;
 }
 
-// bucket-sorted entry list.  entries[pos] = scalar index | sign << 31
+// bucket-sorted entry list.  entries[pos] = scalar index | sign << 31, and in fixed-base
+// mode also the window (which block of the shifted table the point comes from) << 26
 __global__ void __launch_bounds__(512) k_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ local,
                                                  const uint32_t *__restrict__ blockbase, uint32_t *__restrict__ fill,
-                                                 uint32_t *__restrict__ entries, size_t n, int W, int NB, int tile) {
+                                                 uint32_t *__restrict__ entries, size_t n, int W, int NB, int tile, int shared) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, t = blockIdx.z;
-    const size_t base = (size_t)t * W + w;
+    const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
+    const uint32_t wtag = shared ? (uint32_t)w << 26 : 0u;
     const int16_t *dg = digits + base * n;
     for (int b = threadIdx.x; b < NB; b += blockDim.x) lds[b] = 0;
     __syncthreads();
@@ -279,7 +316,7 @@ __global__ void __launch_bounds__(512) k_scatter(const int16_t *__restrict__ dig
     for (int b = threadIdx.x; b < NB; b += blockDim.x) {
         uint32_t c = lds[b];
         if (c) {
-            size_t g = base * NB + b;
+            size_t g = bset * NB + b;
             lds[b] = local[g] + blockbase[g >> 10] + atomicAdd(&fill[g], c);
         }
     }
@@ -288,7 +325,7 @@ __global__ void __launch_bounds__(512) k_scatter(const int16_t *__restrict__ dig
         int d = dg[i];
         if (d != 0) {
             uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
-            entries[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+            entries[pos] = (uint32_t)i | wtag | (d < 0 ? 0x80000000u : 0u);
         }
     }
 }
@@ -337,7 +374,7 @@ __device__ __forceinline__ uint32_t find_bucket(const level_ref &lv, uint32_t t,
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ counts, level_ref ent, level_ref lv0,
                                                     ge_rec *__restrict__ parts, uint32_t nblk, uint32_t ne, int ls0,
-                                                    seg_map map) {
+                                                    seg_map map, uint32_t wstride) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= lv0.base[nblk]) return;
     uint32_t rank;
@@ -351,7 +388,11 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
     for (uint32_t e = off + lo; e < off + hi; e++) {
         uint32_t en = entries[e];
         ge_aniels q;
-        load_aniels(q, map_record(map, en & 0x7fffffffu));
+        // variable-base: wstride = 0 and the entry is index | sign; fixed-base: window w's copy
+        // of point i (2^(c w) P_i) lives wstride records further per window
+        const uint32_t idx = wstride ? (en & 0x03ffffffu) : (en & 0x7fffffffu);
+        const uint32_t win = wstride ? ((en >> 26) & 31u) : 0u;   // fixed-base tables have <= 28 windows
+        load_aniels(q, map_record(map, idx) + (size_t)win * wstride);
         ge_madd(acc, acc, q, (en >> 31) != 0);
     }
     store_ge(parts + t, acc);
@@ -380,8 +421,8 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t *__restrict__ cou
 }
 
 struct levels_dev {
-    level_ref lv[6];
-    const ge_rec *parts[6];
+    level_ref lv[MAX_LEVELS];
+    const ge_rec *parts[MAX_LEVELS];
     int nlevels;          // levels 0 .. nlevels-1 exist
 };
 
@@ -452,23 +493,47 @@ static int ilog2(size_t x) {
     return r;
 }
 
-msm_plan make_plan(size_t n, int T, const msm_tuning &tune) {
-    const int force_c = tune.c;
+// variable-base window size: the divisor of 252 that minimises windows * (n + 4 * buckets)
+static int auto_window(size_t n) {
+    static const int cand[] = {4, 6, 7, 9, 12, 14};
+    int best = 4;
+    double best_cost = 1e300;
+    for (int c : cand) {
+        double cost = (double)windows_for(c) * ((double)n + 4.0 * (double)(1u << (c - 1)));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+// fixed-base window size for a generator table of `points` points (shared bucket set:
+// bucket overhead is paid once, not per window)
+// (at most 32 windows: the entry word keeps the window in 5 bits)
+int fixed_base_window(size_t points) {
+    if (points <= ((size_t)1 << 12)) return 9;
+    if (points <= ((size_t)1 << 15)) return 12;
+    return 14;
+}
+int fixed_base_windows(int c) { return windows_for(c); }
+
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c) {
     msm_plan pl{};
-    int lg = n > 1 ? ilog2(n - 1) + 1 : 0;   // ceil(log2 n)
-    int c = lg - 5;
-    if (c < 4) c = 4;
-    if (c > 14) c = 14;
-    if (force_c >= 2 && force_c <= 14) c = force_c;
+    int c = auto_window(n);
+    if (tune.c >= 2 && tune.c <= 14) c = tune.c;
+    if (fixed_c) c = fixed_c;
     pl.c = c;
-    pl.W = 255 / c + 1;
+    pl.W = windows_for(c);
+    pl.Wb = fixed_c ? 1 : pl.W;
     pl.NB = 1 << (c - 1);
     pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 8) ? tune.ls0 : 4;
     pl.ls1 = (tune.ls1 >= 1 && tune.ls1 <= 8) ? tune.ls1 : 4;
     pl.P = 1 << pl.ls0;
-    // passes: S0 * S1^R >= n  (a bucket never holds more than n entries)
+    // passes: S0 * S1^R >= the most entries one bucket can hold
+    const size_t worst = fixed_c ? n * (size_t)pl.W : n;
     int R = 0;
-    while (((size_t)1 << (pl.ls0 + pl.ls1 * R)) < n) R++;
+    while (((size_t)1 << (pl.ls0 + pl.ls1 * R)) < worst) R++;
     pl.R = R;
     int tile = 4096;
     while (tile < 32768 && (size_t)tile * 64 < n) tile *= 2;
@@ -543,9 +608,9 @@ void msm_job_destroy(bpg_msm_job *j) {
 }
 
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalars, size_t n, int T, bool scalars_on_host,
-               bpg_msm_job **out_job) {
+               bpg_msm_job **out_job, msm_fixed_base fb) {
     if (!ctx || !segs || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
-    if (n >= ((size_t)1 << 28)) return BPG_EINVAL;
+    if (n >= ((size_t)1 << 28) || (fb.c && (n >= ((size_t)1 << 26) || fb.wstride >= ((size_t)1 << 32)))) return BPG_EINVAL;
     seg_map map{};
     {
         size_t acc = 0;
@@ -565,22 +630,23 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if (!lane) return BPG_EDEVICE;
     bpg_msm_job *j = acquire_job(lane);
     if (!j) return BPG_EDEVICE;
-    msm_plan pl = make_plan(n, T, ctx->tune);
+    msm_plan pl = make_plan(n, T, ctx->tune, fb.c);
     j->plan = pl;
-    const size_t NE = (size_t)T * pl.W * pl.NB;           // buckets
+    const size_t NE = (size_t)T * pl.Wb * pl.NB;          // buckets
     const size_t M = (size_t)T * pl.W * n;                // upper bound on entries
     if (M >= ((size_t)1 << 32) || NE >= ((size_t)1 << 30)) return BPG_EINVAL;
     const size_t nblk = (NE + 1023) / 1024;
     const int logchunk = ilog2(pl.chunk), lognch = ilog2(pl.nchunks), per0 = logchunk + 1;
     const int nlevels = pl.R + 1;                          // levels 0..R
-    if (nlevels > 6) return BPG_EINVAL;
+    if (nlevels > MAX_LEVELS) return BPG_EINVAL;
     int rc;
-    if ((rc = grow((void **)&j->d_out, &j->cap_out, (size_t)T * pl.W * pl.outs * sizeof(ge_rec)))) return rc;
-    if ((size_t)T * pl.W * pl.outs * sizeof(ge_rec) > j->cap_hout) {
+    const size_t out_bytes = (size_t)T * pl.Wb * pl.outs * sizeof(ge_rec);
+    if ((rc = grow((void **)&j->d_out, &j->cap_out, out_bytes))) return rc;
+    if (out_bytes > j->cap_hout) {
         if (j->h_out) (void)hipHostFree(j->h_out);
         j->h_out = nullptr;
         j->cap_hout = 0;
-        size_t want = (size_t)T * pl.W * pl.outs * sizeof(ge_rec) * 2;
+        size_t want = out_bytes * 2;
         BPG_CHECK_HIP(hipHostMalloc((void **)&j->h_out, want, hipHostMallocDefault));
         j->cap_hout = want;
     }
@@ -595,7 +661,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         return BPG_OK;
     }
     // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
-    size_t cap_lv[6], part_off[6], part_total = 0;
+    size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS], part_total = 0;
     cap_lv[0] = (M >> pl.ls0) + NE + 1;
     for (int r = 1; r < nlevels; r++) cap_lv[r] = cap_lv[r - 1] / 2 + 1;
     for (int r = 0; r < nlevels; r++) {
@@ -608,7 +674,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if ((rc = grow((void **)&j->d_counts, &j->cap_counts, (2 * NE + (size_t)(nlevels + 1) * lvl_words + 16) * sizeof(uint32_t))))
         return rc;
     if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
-    if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.W * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
+    if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.Wb * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
     const uint32_t *d_sc = (const uint32_t *)d_scalars;
     if (scalars_on_host) {
         if ((rc = grow(&j->d_stage, &j->cap_stage, (size_t)T * n * 32))) return rc;
@@ -621,17 +687,17 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
     BPG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * NE * sizeof(uint32_t), s));
 
+    const int shared = fb.c ? 1 : 0;
     dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n);
     dim3 tgrid(pl.ntiles, pl.W, T);
     size_t hist_lds = (size_t)pl.NB * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_hist, tgrid, dim3(512), hist_lds, s, j->d_digits, counts, n, pl.W, pl.NB, pl.tile);
-    // entry offsets (level -1) and level-0 thread offsets
-    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(0), lv_tot(0), NE, -1, pl.ls0, pl.ls1);
-    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(0), nblk);
-    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(1), lv_tot(1), NE, 0, pl.ls0, pl.ls1);
-    hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(1), nblk);
+    hipLaunchKernelGGL(k_hist, tgrid, dim3(512), hist_lds, s, j->d_digits, counts, n, pl.W, pl.NB, pl.tile, shared);
+    // entry offsets (level -1) and the thread offsets of every pass (levels 0..R), two launches
+    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, pl.ls0,
+                       pl.ls1);
+    hipLaunchKernelGGL(k_scan_b, dim3(nlevels + 1), dim3(1024), 0, s, lvl_base, lvl_words, NE, nblk);
     hipLaunchKernelGGL(k_scatter, tgrid, dim3(512), hist_lds, s, j->d_digits, lv_local(0), lv_tot(0), fill, j->d_entries, n,
-                       pl.W, pl.NB, pl.tile);
+                       pl.W, pl.NB, pl.tile, shared);
     level_ref ent{lv_local(0), lv_tot(0)};
     levels_dev L{};
     L.nlevels = nlevels;
@@ -641,24 +707,21 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     }
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries,
-                       counts, ent, L.lv[0], j->d_partials + part_off[0], (uint32_t)nblk, (uint32_t)NE, pl.ls0, map);
+                       counts, ent, L.lv[0], j->d_partials + part_off[0], (uint32_t)nblk, (uint32_t)NE, pl.ls0, map,
+                       (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
-    for (int r = 1; r < nlevels; r++) {
-        hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lv_local(r + 1), lv_tot(r + 1), NE, r,
-                           pl.ls0, pl.ls1);
-        hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(1024), 0, s, lv_tot(r + 1), nblk);
+    for (int r = 1; r < nlevels; r++)
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r],
                            j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
                            pl.ls0, pl.ls1);
-    }
     ge_rec *a_out = pl.nchunks == 1 ? j->d_out : j->d_chunk;
-    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.W, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,
-                       pl.chunk, logchunk, pl.W, pl.ls0, pl.ls1);
+    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,
+                       pl.chunk, logchunk, pl.Wb, pl.ls0, pl.ls1);
     if (pl.nchunks > 1)
-        hipLaunchKernelGGL(k_tail_b, dim3(pl.W, T), dim3(320), (size_t)pl.nchunks * per0 * 128, s, j->d_chunk, j->d_out,
-                           pl.nchunks, lognch, per0, pl.W);
+        hipLaunchKernelGGL(k_tail_b, dim3(pl.Wb, T), dim3(320), (size_t)pl.nchunks * per0 * 128, s, j->d_chunk, j->d_out,
+                           pl.nchunks, lognch, per0, pl.Wb);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, (size_t)T * pl.W * pl.outs * sizeof(ge_rec), hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
     return BPG_OK;
 }
@@ -677,9 +740,10 @@ int msm_wait(bpg_msm_job *j, uint8_t *out, bool partial) {
         ge_identity(acc);
         if (pl.n != 0) {
             const int C = pl.c, outs = pl.outs;
-            const ge_rec *base = j->h_out + (size_t)t * pl.W * outs;
-            // out layout per window: [total, S_0, ..., S_{C-2}]; total and S_0 weigh 2^(C w), S_j weighs 2^(C w + j)
-            for (int pos = C * (pl.W - 1) + C - 2; pos >= 0; pos--) {
+            const ge_rec *base = j->h_out + (size_t)t * pl.Wb * outs;
+            // out layout per bucket set: [total, S_0, ..., S_{C-2}]; total and S_0 weigh 2^(C w), S_j weighs 2^(C w + j)
+            // (fixed-base: one set, w = 0 -- the window weights are in the table)
+            for (int pos = C * (pl.Wb - 1) + C - 2; pos >= 0; pos--) {
                 ge_double(acc, acc);
                 int w = pos / C, jbit = pos - w * C;
                 if (jbit <= C - 2) {

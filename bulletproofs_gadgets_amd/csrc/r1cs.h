@@ -119,6 +119,9 @@ struct Gens {
     bpg_points *table = nullptr;
     void *d_comb = nullptr;           // radix-16 comb tables of B and B_blinding (Pedersen kernel)
     size_t capacity = 0;
+    // fixed-base MSM: the table holds fb_windows blocks of 2*capacity+2 records, block w = 2^(fb_c w) * block 0
+    int fb_c = 0, fb_windows = 0;
+    size_t npoints() const { return 2 * capacity + 2; }
     size_t off_G() const { return 0; }
     size_t off_H() const { return capacity; }
     size_t off_B() const { return 2 * capacity; }

@@ -582,7 +582,9 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out) {
     tbl->ctx = ctx;
     tbl->n = 2 * capacity + 2;
     tbl->d_table = nullptr;
-    hipError_t e = hipMalloc((void **)&tbl->d_table, tbl->n * sizeof(aniels_rec));
+    g->fb_c = fixed_base_window(tbl->n);
+    g->fb_windows = fixed_base_windows(g->fb_c);
+    hipError_t e = hipMalloc((void **)&tbl->d_table, (size_t)g->fb_windows * tbl->n * sizeof(aniels_rec));
     if (e != hipSuccess) {
         set_last_error("hipMalloc(generator table)", e);
         delete tbl;
@@ -612,6 +614,7 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out) {
     s3.absorb(Benc, 32);
     s3.squeeze(h, 64);
     if ((rc = table_write_uniform(ctx, tbl->d_table + g->off_Bb(), h, 1))) return rc;
+    if ((rc = table_build_shifted(ctx, tbl->d_table, tbl->n, g->fb_c, g->fb_windows))) return rc;
     GensExtra ex;
     BPG_CHECK_HIP(hipMalloc((void **)&ex.d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
     hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), ex.d_comb);
@@ -728,6 +731,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
     const aniels_rec *tbl = gens_->table->d_table;
+    const msm_fixed_base fb{gens_->fb_c, gens_->npoints()};
     const size_t n = a_L_.size(), m = v_.size();
     const size_t np = next_pow2(n ? n : 1);
     if (gens_->capacity < np) return BPG_EGENS;
@@ -785,7 +789,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     {
         msm_seg segs[3] = {{tbl + gens_->off_Bb(), 1}, {tbl + gens_->off_G(), n}, {tbl + gens_->off_H(), n}};
         bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, segs, 3, d_rows, N1, 3, false, &job))) return rc;
+        if ((rc = msm_submit(ctx, segs, 3, d_rows, N1, 3, false, &job, fb))) return rc;
         uint8_t out[96];
         if ((rc = msm_wait(job, out, false))) return rc;
         memcpy(P.A_I1, out, 32);
@@ -880,7 +884,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
         BPG_CHECK_HIP(hipStreamSynchronize(s));
         msm_seg segs[3] = {{tbl + gens_->off_G(), np}, {tbl + gens_->off_H(), np}, {tbl + gens_->off_B(), 1}};
         bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, segs, 3, d_rowLR, NR, 2, false, &job))) return rc;
+        if ((rc = msm_submit(ctx, segs, 3, d_rowLR, NR, 2, false, &job, fb))) return rc;
         uint8_t out[64];
         if ((rc = msm_wait(job, out, false))) return rc;
         memcpy(&P.L_vec[32 * k], out, 32);
@@ -1038,12 +1042,18 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     for (size_t k = 0; k < lg; k++) tail.push_back(u_inv_sq[k]);                  // R
     BPG_CHECK_HIP(hipMemcpyAsync(d_sc + 2 * np, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
+    // generators: fixed-base MSM over the shifted table; per-proof points: variable-base MSM
     const aniels_rec *tbl = gens->table->d_table;
-    msm_seg segs[4] = {{tbl + gens->off_G(), np}, {tbl + gens->off_H(), np}, {tbl + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
-    bpg_msm_job *job = nullptr;
-    if ((rc = msm_submit(ctx, segs, 4, d_sc, NS, 1, false, &job))) return rc;
-    uint8_t out[32];
-    if ((rc = msm_wait(job, out, false))) return rc;
+    msm_seg fixed[3] = {{tbl + gens->off_G(), np}, {tbl + gens->off_H(), np}, {tbl + gens->off_B(), 2}};
+    msm_seg dynseg{lane->d_dyn, ndyn};
+    bpg_msm_job *job_f = nullptr, *job_d = nullptr;
+    if ((rc = msm_submit(ctx, fixed, 3, d_sc, 2 * np + 2, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()})))
+        return rc;
+    if ((rc = msm_submit(ctx, &dynseg, 1, d_sc + 2 * np + 2, ndyn, 1, false, &job_d))) return rc;
+    uint8_t parts[256], out[32];
+    if ((rc = msm_wait(job_f, parts, true))) return rc;
+    if ((rc = msm_wait(job_d, parts + 128, true))) return rc;
+    if ((rc = combine_partials(parts, 2, out))) return rc;
     uint8_t acc = 0;
     for (int i = 0; i < 32; i++) acc |= out[i];
     return acc ? BPG_EVERIFY : BPG_OK;
