@@ -87,6 +87,7 @@ def lib():
         "bpg_verifier_cs": (vp, [vp]),
         "bpg_verifier_commit": (ci, [vp, cp, u64p]),
         "bpg_verifier_commit_batch": (ci, [vp, cp, sz, u64p]),
+        "bpg_verifier_verify_batch": (ci, [vp, vp, vp, sz, vp, RNG_FN, vp]),
         "bpg_verifier_verify": (ci, [vp, vp, cp, sz, RNG_FN, vp]),
         "bpg_verifier_stats": (ci, [vp, psz, psz]),
         "bpg_cs_multiply": (ci, [vp, u64p, cp, sz, u64p, cp, sz, u64p]),

@@ -169,6 +169,14 @@ class Prover : public ConstraintSystem {
     std::vector<sc> a_L_, a_R_, a_O_, v_, v_blinding_;
 };
 
+// scalars of one proof's verification equation (see Verifier::prepare)
+struct VerifyRow {
+    sc *d_sc = nullptr;
+    size_t np = 0;
+    std::vector<sc> tail;
+    std::vector<uint8_t> dyn;
+};
+
 class Verifier : public ConstraintSystem {
   public:
     Verifier(const void *label, size_t label_len);
@@ -179,6 +187,7 @@ class Verifier : public ConstraintSystem {
     bool is_prover() const override { return false; }
     // Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng); BPG_OK or BPG_EVERIFY / BPG_EGENS / ...
     int verify(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user);
+    int prepare(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user, VerifyRow &out);
     size_t num_multipliers() const { return num_vars_; }
     size_t num_constraints() const { return cs_.num_constraints; }
 
@@ -188,6 +197,9 @@ class Verifier : public ConstraintSystem {
     size_t num_vars_ = 0;
     std::vector<uint8_t> V_;
 };
+
+// k proofs, one combined multiscalar multiplication (BASELINE config 5); BPG_OK iff all verify
+int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *gens, rng_fill_fn rng, void *rng_user);
 
 // ---- zerocaf "Sonny" curve over F_l (witness values only) -------------------------
 struct SonnyPoint {

@@ -282,6 +282,16 @@ __global__ void __launch_bounds__(256) k_verify_scalars(verify_args A, const sc 
     block_sum<1>(d, partial);
 }
 
+// batch verification: acc[i] += rho * row[i]
+__global__ void __launch_bounds__(256) k_axpy(uint32_t n, sc rho, const sc *__restrict__ row, sc *__restrict__ acc) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    sc r = ld_sc(row + i), a = ld_sc(acc + i), t;
+    sc_mul(t, rho, r);
+    sc_add(a, a, t);
+    st_sc(acc + i, a);
+}
+
 // K3: fixed-base Pedersen commitments v B + r B~ with radix-16 comb tables, compressed on the device.
 // comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels)
 __global__ void __launch_bounds__(64) k_pedersen(const aniels_rec *__restrict__ comb, const sc *__restrict__ scalars /* [m][2] */,
@@ -933,7 +943,11 @@ ConstraintSystem::Triple Verifier::allocate_multiplier(const Scalar *, const Sca
     return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
 }
 
-int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
+// Everything up to the final multiscalar multiplication: transcript replay, challenges,
+// and the scalar that multiplies every point of the verification equation.  out.d_sc
+// (device, in the lane's arena) holds the 2 n+ generator scalars [g | h];
+// out.tail the scalars of [B, B~, per-proof points]; out.dyn those points (compressed).
+int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *rng_user, VerifyRow &out) {
     bpg_ctx *ctx = gens->ctx;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
@@ -983,8 +997,7 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
 
     // per-proof points -> this lane's point scratch: [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T.. | L.. | R..]
     const size_t ndyn = 6 + m + 5 + 2 * lg;
-    int rc = grow((void **)&lane->d_dyn, &lane->dyn_cap, ndyn * sizeof(aniels_rec));
-    if (rc) return rc;
+    int rc;
     std::vector<uint8_t> dyn;
     dyn.reserve(32 * ndyn);
     auto put = [&](const uint8_t *p) { dyn.insert(dyn.end(), p, p + 32); };
@@ -993,9 +1006,6 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     put(P.T_1); put(P.T_3); put(P.T_4); put(P.T_5); put(P.T_6);
     dyn.insert(dyn.end(), P.L_vec.begin(), P.L_vec.end());
     dyn.insert(dyn.end(), P.R_vec.begin(), P.R_vec.end());
-    uint32_t bad = 0;
-    if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
-    if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
 
     FlatPlan fp;
     build_flat_plan(cs_, (uint32_t)n, (uint32_t)m, true, fp);
@@ -1040,16 +1050,33 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     tail.push_back((rxx * xxx).v); tail.push_back((rxx * xx * xx).v);             // T_1 T_3 T_4 T_5 T_6
     for (size_t k = 0; k < lg; k++) tail.push_back(u_sq[k]);                      // L
     for (size_t k = 0; k < lg; k++) tail.push_back(u_inv_sq[k]);                  // R
-    BPG_CHECK_HIP(hipMemcpyAsync(d_sc + 2 * np, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
+    out.d_sc = d_sc;
+    out.np = np;
+    out.tail = std::move(tail);
+    out.dyn = std::move(dyn);
+    return BPG_OK;
+}
+
+// generators: fixed-base MSM over the shifted table; per-proof points: variable-base MSM.
+// d_gh = [g[0..ng) | h[0..nh)] device scalars; tail = scalars of [B, B~ | dyn points].
+static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, size_t nh, sc *d_tail, const std::vector<sc> &tail,
+                      const std::vector<uint8_t> &dyn) {
+    bpg_ctx *ctx = gens->ctx;
+    hipStream_t s = lane->stream;
+    const size_t ndyn = dyn.size() / 32;
+    int rc;
+    if ((rc = grow((void **)&lane->d_dyn, &lane->dyn_cap, (ndyn + 1) * sizeof(aniels_rec)))) return rc;
+    uint32_t bad = 0;
+    if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
+    if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
+    BPG_CHECK_HIP(hipMemcpyAsync(d_tail, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    // generators: fixed-base MSM over the shifted table; per-proof points: variable-base MSM
     const aniels_rec *tbl = gens->table->d_table;
-    msm_seg fixed[3] = {{tbl + gens->off_G(), np}, {tbl + gens->off_H(), np}, {tbl + gens->off_B(), 2}};
-    msm_seg dynseg{lane->d_dyn, ndyn};
+    msm_seg gh[2] = {{tbl + gens->off_G(), ng}, {tbl + gens->off_H(), nh}};
+    msm_seg rest[2] = {{tbl + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
     bpg_msm_job *job_f = nullptr, *job_d = nullptr;
-    if ((rc = msm_submit(ctx, fixed, 3, d_sc, 2 * np + 2, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()})))
-        return rc;
-    if ((rc = msm_submit(ctx, &dynseg, 1, d_sc + 2 * np + 2, ndyn, 1, false, &job_d))) return rc;
+    if ((rc = msm_submit(ctx, gh, 2, d_gh, ng + nh, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()}))) return rc;
+    if ((rc = msm_submit(ctx, rest, 2, d_tail, 2 + ndyn, 1, false, &job_d))) return rc;
     uint8_t parts[256], out[32];
     if ((rc = msm_wait(job_f, parts, true))) return rc;
     if ((rc = msm_wait(job_d, parts + 128, true))) return rc;
@@ -1057,6 +1084,65 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     uint8_t acc = 0;
     for (int i = 0; i < 32; i++) acc |= out[i];
     return acc ? BPG_EVERIFY : BPG_OK;
+}
+
+int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
+    bpg_lane *lane = lane_of(gens->ctx);
+    if (!lane) return BPG_EDEVICE;
+    VerifyRow row;
+    int rc = prepare(P, gens, rng_fn, rng_user, row);
+    if (rc) return rc;
+    return verify_msm(lane, gens, row.d_sc, row.np, row.np, row.d_sc + 2 * row.np, row.tail, row.dyn);
+}
+
+// One combined multiscalar multiplication for k proofs: sum_j rho_j * (verification equation j)
+// with rho_j drawn from the caller's RNG.  BPG_OK iff every proof verifies (up to 2^-250).
+int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
+    if (!k) return BPG_OK;
+    bpg_lane *lane = lane_of(gens->ctx);
+    if (!lane) return BPG_EDEVICE;
+    hipStream_t s = lane->stream;
+    const size_t cap = gens->capacity;
+    sc *d_acc = nullptr, *d_tail = nullptr;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_acc, 2 * cap * 32));
+    struct Free {
+        sc *&a, *&b;
+        ~Free() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+        }
+    } guard{d_acc, d_tail};
+    BPG_CHECK_HIP(hipMemsetAsync(d_acc, 0, 2 * cap * 32, s));
+    std::vector<sc> tail(2);
+    std::vector<uint8_t> dyn;
+    size_t np_max = 0;
+    Scalar accB(0), accBb(0);
+    for (size_t j = 0; j < k; j++) {
+        VerifyRow row;
+        int rc = vs[j]->prepare(proofs[j], gens, rng_fn, rng_user, row);
+        if (rc) return rc;
+        uint8_t wide[64] = {0};
+        rng_fn(rng_user, wide, 32);
+        sc lo, hi, rho_sc;
+        sc_frombytes(lo, wide);
+        sc_frombytes(hi, wide + 32);
+        sc_reduce512(rho_sc, lo, hi);
+        const Scalar rho = j == 0 ? Scalar(1) : Scalar(rho_sc);
+        hipLaunchKernelGGL(k_axpy, dim3(grid256(row.np)), dim3(256), 0, s, (uint32_t)row.np, rho.v, row.d_sc, d_acc);
+        hipLaunchKernelGGL(k_axpy, dim3(grid256(row.np)), dim3(256), 0, s, (uint32_t)row.np, rho.v, row.d_sc + row.np, d_acc + cap);
+        BPG_CHECK_HIP(hipGetLastError());
+        accB += rho * Scalar(row.tail[0]);
+        accBb += rho * Scalar(row.tail[1]);
+        for (size_t i = 2; i < row.tail.size(); i++) tail.push_back((rho * Scalar(row.tail[i])).v);
+        dyn.insert(dyn.end(), row.dyn.begin(), row.dyn.end());
+        if (row.np > np_max) np_max = row.np;
+        BPG_CHECK_HIP(hipStreamSynchronize(s));     // the next prepare() reuses the lane's arena
+    }
+    tail[0] = accB.v;
+    tail[1] = accBb.v;
+    BPG_CHECK_HIP(hipMalloc((void **)&d_tail, tail.size() * 32));
+    // [g[0..cap) | h[0..np_max)]: g scalars beyond np_max are zero and produce no bucket entries
+    return verify_msm(lane, gens, d_acc, cap, np_max, d_tail, tail, dyn);
 }
 
 }  // namespace bpg

@@ -196,6 +196,20 @@ int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, s
         return v->v->verify(P, gens->g, rng, rng_user);
     });
 }
+int bpg_verifier_verify_batch(bpg_verifier *const *verifiers, const uint8_t *const *proofs, const size_t *proof_lens, size_t k,
+                              bpg_gens *gens, bpg_rng_fn rng, void *rng_user) {
+    if (!gens || !rng || (k && (!verifiers || !proofs || !proof_lens))) return BPG_EINVAL;
+    return guarded([&] {
+        std::vector<R1CSProof> P(k);
+        std::vector<Verifier *> vs(k);
+        for (size_t j = 0; j < k; j++) {
+            if (!verifiers[j] || !proofs[j]) return BPG_EINVAL;
+            if (!R1CSProof::from_bytes(proofs[j], proof_lens[j], P[j])) return BPG_EFORMAT;
+            vs[j] = verifiers[j]->v;
+        }
+        return verify_batch(vs.data(), P.data(), k, gens->g, rng, rng_user);
+    });
+}
 int bpg_verifier_stats(const bpg_verifier *v, size_t *multipliers, size_t *constraints) {
     if (!v) return BPG_EINVAL;
     if (multipliers) *multipliers = v->v->num_multipliers();

@@ -254,6 +254,24 @@ class Verifier(_CS):
             pass
 
 
+def verify_batch(verifiers, proofs, bp_gens, external_rng=b""):
+    """k proofs, one combined multiscalar multiplication (BASELINE config 5).  True iff every proof
+    verifies; raises VerificationError if at least one does not.  external_rng: >= 64 * k bytes."""
+    k = len(verifiers)
+    assert len(proofs) == k
+    raws = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in proofs]
+    vs = (ctypes.c_void_p * max(k, 1))(*[v._h for v in verifiers])
+    bufs = [ctypes.create_string_buffer(r, len(r)) for r in raws]
+    ps = (ctypes.c_void_p * max(k, 1))(*[ctypes.addressof(b) for b in bufs])
+    lens = (ctypes.c_size_t * max(k, 1))(*[len(r) for r in raws])
+    cb = _rng_cb(external_rng if len(external_rng) >= 64 * k else external_rng + bytes(64 * k - len(external_rng)))
+    rc = lib().bpg_verifier_verify_batch(vs, ps, lens, k, bp_gens._h, cb, None)
+    if rc == _native.EVERIFY:
+        raise VerificationError()
+    check(rc)
+    return True
+
+
 def _xyzt(p):
     return _sc(p.X) + _sc(p.Y) + _sc(p.Z) + _sc(p.T)
 
@@ -378,5 +396,5 @@ def transcript_kat(label, msg_label, msg, challenge_label, n):
 
 
 __all__ = ["BpgError", "BulletproofGens", "LinearCombination", "LC", "Variable", "Prover", "Verifier", "Proof",
-           "VerificationError", "SonnyEdwardsPointGadget", "SonnyRistrettoPointGadget", "binary_constrain_gadget",
+           "VerificationError", "verify_batch", "SonnyEdwardsPointGadget", "SonnyRistrettoPointGadget", "binary_constrain_gadget",
            "nonzero_gadget", "sk_knowledge_gadget", "transcript_kat"]

@@ -169,6 +169,12 @@ int bpg_verifier_commit_batch(bpg_verifier *v, const uint8_t *V32, size_t m, uin
 /* Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng)   ref: tests/edwards_point.rs:79,158,242,345,412; scalar.rs:63; sk_know_gadget.rs:86
  * BPG_OK | BPG_EVERIFY (R1CSError::VerificationError) | BPG_EFORMAT | BPG_EGENS */
 int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, size_t proof_len, bpg_rng_fn rng, void *rng_user);
+/* k proofs checked by ONE combined multiscalar multiplication: sum_j rho_j * (verification equation of proof j),
+ * rho_j from `rng` (BASELINE config 5; SURVEY 8b bpg_r1cs_verify_batch).  Each verifier carries its own circuit and
+ * commitments, as for bpg_verifier_verify, and is consumed the same way.  BPG_OK iff every proof verifies;
+ * BPG_EVERIFY says at least one does not (verify them one by one to find which). */
+int bpg_verifier_verify_batch(bpg_verifier *const *verifiers, const uint8_t *const *proofs, const size_t *proof_lens, size_t k,
+                              bpg_gens *gens, bpg_rng_fn rng, void *rng_user);
 int bpg_verifier_stats(const bpg_verifier *v, size_t *multipliers, size_t *constraints);
 
 /* ConstraintSystem::multiply / allocate_multiplier / constrain

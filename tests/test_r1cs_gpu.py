@@ -223,3 +223,80 @@ def test_concurrent_provers_share_generators(gbe, obe, rnd):
         for i in range(6):
             assert res[i][0] and serial[i][0]
             assert res[i][1].to_bytes() == serial[i][1].to_bytes()
+
+
+def _radd_circuit(be, cs, p1, p2, p3):
+    g1, g2, g3 = (be.RistrettoGadget.from_point(p, cs) for p in (p1, p2, p3))
+    g3.equals(cs, g1.add(cs, g2))
+
+
+def _eadd_circuit(be, cs, p1, p2, p3):
+    g1, g2, g3 = (be.EdwardsGadget.from_point(p) for p in (p1, p2, p3))
+    g3.equal(g1.add(g2, cs), cs)
+
+
+def test_verify_batch(gbe, obe, rnd):
+    """BASELINE config 5: k proofs (mixed circuits and sizes: 134 -> 256 and 16 multipliers, with and
+    without commitments) checked by ONE combined multiscalar multiplication.  The batch verdict must be
+    the AND of the per-proof verdicts (which the tests above pin against the oracle)."""
+    from bulletproofs_gadgets_amd import r1cs as g
+    bp = gbe.bp_gens(256)
+    items = []          # (build verifier, proof)
+    for i in range(5):
+        a, b = sonny.random_point(rnd), sonny.random_point(rnd)
+        if i % 2 == 0:
+            ra, rb = sonny.RistrettoPoint(a), sonny.RistrettoPoint(b)
+            ok, proof = rc.ristretto_add_roundtrip(gbe, ra, rb, ra + rb, rng=R.SeededRng(b"vb%d" % i), cap=256)
+            items.append((lambda ra=ra, rb=rb: (b"RistrettoAdd", lambda v: _radd_circuit(gbe, v, ra, rb, ra + rb)), proof))
+        else:
+            ok, proof = rc.addition_roundtrip(gbe, a, b, a + b, rng=R.SeededRng(b"vb%d" % i), cap=256)
+            items.append((lambda a=a, b=b: (b"Point Addition", lambda v: _eadd_circuit(gbe, v, a, b, a + b)), proof))
+        assert ok
+    # one proof with commitments (m = 8)
+    A = sonny.random_point(rnd)
+    p2 = gbe.Prover(b"PointDouble")
+    srng = R.SeededRng(b"vbc")
+    g1, c1 = gbe.EdwardsGadget.prover_commit_to_sonny_edwards_point(p2, A, srng)
+    g2, c2 = gbe.EdwardsGadget.prover_commit_to_sonny_edwards_point(p2, A, srng)
+    g1.equal(g2, p2)
+    cproof = p2.prove(bp, bytes(32))
+
+    def commit_circuit(v):
+        h1 = gbe.EdwardsGadget.verifier_commit_to_sonny_edwards_point(v, c1)
+        h2 = gbe.EdwardsGadget.verifier_commit_to_sonny_edwards_point(v, c2)
+        h1.equal(h2, v)
+    items.append((lambda: (b"PointDouble", commit_circuit), cproof))
+
+    def verifiers():
+        out = []
+        for mk, _ in items:
+            label, circuit = mk()
+            v = gbe.Verifier(label)
+            circuit(v)
+            out.append(v)
+        return out
+    proofs = [p for _, p in items]
+    ext = bytes(range(1, 65)) * len(items)
+    assert g.verify_batch(verifiers(), proofs, bp, ext)
+    assert g.verify_batch([], [], bp)
+    assert g.verify_batch(verifiers()[:1], proofs[:1], bp, ext)
+    # any single bad proof fails the whole batch, wherever it sits
+    for pos in (0, 3, len(items) - 1):
+        raw = bytearray(proofs[pos].to_bytes())
+        raw[1 + 32 * 8 + 5] ^= 4            # t_x
+        bad = list(proofs)
+        bad[pos] = g.Proof(bytes(raw))
+        with pytest.raises(g.VerificationError):
+            g.verify_batch(verifiers(), bad, bp, ext)
+    # proofs swapped between two statements of the same shape
+    sw = list(proofs)
+    sw[0], sw[2] = sw[2], sw[0]
+    with pytest.raises(g.VerificationError):
+        g.verify_batch(verifiers(), sw, bp, ext)
+    # a point that does not decode
+    raw = bytearray(proofs[1].to_bytes())
+    raw[1:33] = b"\xff" * 32
+    bad = list(proofs)
+    bad[1] = g.Proof(bytes(raw))
+    with pytest.raises(g.VerificationError):
+        g.verify_batch(verifiers(), bad, bp, ext)
