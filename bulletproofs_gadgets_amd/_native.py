@@ -27,6 +27,7 @@ class BpgError(RuntimeError):
 _lib = None
 # bpg_rng_fn: void (*)(void *user, uint8_t *out, size_t n)
 RNG_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 
 def lib():
@@ -71,6 +72,7 @@ def lib():
     ci = ctypes.c_int
     sigs.update({
         "bpg_gens_create": (ci, [vp, sz, sz, pvp]),
+        "bpg_gens_create_sharded": (ci, [vp, sz, sz, ci, ci, EXCHANGE_FN, vp, pvp]),
         "bpg_gens_free": (None, [vp]),
         "bpg_gens_capacity": (sz, [vp]),
         "bpg_gens_export": (ci, [vp, vp, ci, sz, sz, vp]),

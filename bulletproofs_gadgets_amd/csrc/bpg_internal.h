@@ -134,6 +134,7 @@ bpg_lane *lane_of(bpg_ctx *ctx);
 struct msm_seg {
     const aniels_rec *base;
     size_t len;
+    size_t sc_off = 0;     // first scalar of the segment within a target's row (only read when sc_stride != 0)
 };
 // Fixed-base mode: fb.c != 0.  The segments then point into window 0 of a shifted table in
 // which record (w * fb.wstride + i) holds 2^(c w) P_i, and all windows share one bucket set.
@@ -142,7 +143,10 @@ struct msm_fixed_base {
     size_t wstride = 0;
 };
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *scalars, size_t n, int T, bool scalars_on_host,
-               bpg_msm_job **out_job, msm_fixed_base fb = msm_fixed_base());
+               bpg_msm_job **out_job, msm_fixed_base fb = msm_fixed_base(), size_t sc_stride = 0);
+// sc_stride = 0: target t's scalars are the dense row scalars[t*n .. t*n+n), in segment order.
+// sc_stride != 0 (device scalars only): rows are sc_stride scalars apart and segment k reads
+// scalars[t*sc_stride + segs[k].sc_off ..): a rank of a sharded MSM reads its slices in place.
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n);
 int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad);
 // table holds W * npts records with records [0, npts) filled: fills [w * npts + i] = 2^(c w) P_i

@@ -121,15 +121,33 @@ __device__ void lds_bit_tree(uint32_t *lds, int nslots, int nodes, int per, int 
 // the top one included, sees uniform digits.
 __host__ __device__ constexpr int windows_for(int c) { return (252 + c - 1) / c; }
 
+// Where scalar i of a target's row lives: segment k covers [end[k-1], end[k]) of the MSM's
+// index space and starts off[k] scalars into the row; rows are `stride` scalars apart.
+// (Dense rows: off[k] = end[k-1], stride = n.  A rank of a point-range-sharded MSM reads
+// its slices of the full-length rows in place.)
+struct sc_map {
+    uint32_t end[4];
+    uint32_t off[4];
+    size_t stride;
+};
+
 // scalar -> signed c-bit digits.  digits[(t*W + w)*n + i]
 template <int C>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, int16_t *__restrict__ digits,
-                                                size_t n, size_t total) {
+                                                size_t n, size_t total, sc_map sm) {
     constexpr int W = windows_for(C);
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
     size_t t = gid / n, i = gid - t * n;
-    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + gid * 8);
+    uint32_t start = 0, off = sm.off[0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const bool past = i >= sm.end[k - 1];
+        start = past ? sm.end[k - 1] : start;
+        off = past ? sm.off[k] : off;
+    }
+    const size_t src = t * sm.stride + off + (i - start);
+    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + src * 8);
     uint4 lo4 = sp[0], hi4 = sp[1];
     uint32_t v[9] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w, 0u};
     const uint32_t HL[8] = {0x2e7ae9f6u, 0x2c09318du, 0x517bce6bu, 0x0a6f7cefu, 0u, 0u, 0u, 0x08000000u};
@@ -561,14 +579,14 @@ int grow(void **p, size_t *cap, size_t need) {
 }
 
 template <int C>
-static void launch_digits(hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total) {
+static void launch_digits(hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm) {
     unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_digits<C>, dim3(blocks), dim3(256), 0, s, sc, dg, n, total);
+    hipLaunchKernelGGL(k_digits<C>, dim3(blocks), dim3(256), 0, s, sc, dg, n, total, sm);
 }
 
-static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total) {
+static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm) {
     switch (c) {
-#define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total); break;
+#define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total, sm); break;
         BPG_CASE(2) BPG_CASE(3) BPG_CASE(4) BPG_CASE(5) BPG_CASE(6) BPG_CASE(7) BPG_CASE(8) BPG_CASE(9)
         BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14)
 #undef BPG_CASE
@@ -608,23 +626,30 @@ void msm_job_destroy(bpg_msm_job *j) {
 }
 
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalars, size_t n, int T, bool scalars_on_host,
-               bpg_msm_job **out_job, msm_fixed_base fb) {
+               bpg_msm_job **out_job, msm_fixed_base fb, size_t sc_stride) {
     if (!ctx || !segs || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
+    if (sc_stride && scalars_on_host) return BPG_EINVAL;
     if (n >= ((size_t)1 << 28) || (fb.c && (n >= ((size_t)1 << 26) || fb.wstride >= ((size_t)1 << 32)))) return BPG_EINVAL;
     seg_map map{};
+    sc_map smap{};
     {
         size_t acc = 0;
         for (int k = 0; k < 4; k++) {
+            smap.off[k] = 0;
             if (k < nseg) {
                 if (segs[k].len && !segs[k].base) return BPG_EINVAL;
+                if (sc_stride && (segs[k].sc_off + segs[k].len > sc_stride || sc_stride >= ((size_t)1 << 32))) return BPG_EINVAL;
                 map.base[k] = segs[k].base - acc;
+                smap.off[k] = (uint32_t)(sc_stride ? segs[k].sc_off : acc);
                 acc += segs[k].len;
             } else {
                 map.base[k] = nullptr;
             }
             map.len[k] = k < nseg ? (uint32_t)acc : 0xffffffffu;
+            smap.end[k] = map.len[k];
         }
         if (acc != n) return BPG_EINVAL;
+        smap.stride = sc_stride ? sc_stride : n;
     }
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
@@ -688,7 +713,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     BPG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * NE * sizeof(uint32_t), s));
 
     const int shared = fb.c ? 1 : 0;
-    dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n);
+    dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap);
     dim3 tgrid(pl.ntiles, pl.W, T);
     size_t hist_lds = (size_t)pl.NB * sizeof(uint32_t);
     hipLaunchKernelGGL(k_hist, tgrid, dim3(512), hist_lds, s, j->d_digits, counts, n, pl.W, pl.NB, pl.tile, shared);

@@ -114,20 +114,33 @@ class ConstraintSystem {
 // PedersenGens::default() and BulletproofGens::new(cap, 1), resident on one GPU:
 // table = [ G_0..G_{cap-1} | H_0..H_{cap-1} | B | B_blinding ].  Immutable after creation:
 // any number of host threads may prove / verify against one Gens concurrently.
+//
+// Point-range sharding (BASELINE config 4): rank r of `world` holds only the
+// generators lo <= i < hi of G and of H (plus B, B_blinding, which rank 0 alone puts into
+// MSMs).  Every rank runs the same prover / verifier on the same inputs; each MSM is computed
+// over the rank's range and the 128-byte partial sums are all-gathered through `exchange`
+// and added, so every rank sees the same compressed point and the same transcript.
+typedef int (*exchange_fn)(void *user, const uint8_t *mine, size_t bytes, uint8_t *all /* world * bytes, rank-major */);
 struct Gens {
     bpg_ctx *ctx = nullptr;
     bpg_points *table = nullptr;
     void *d_comb = nullptr;           // radix-16 comb tables of B and B_blinding (Pedersen kernel)
     size_t capacity = 0;
-    // fixed-base MSM: the table holds fb_windows blocks of 2*capacity+2 records, block w = 2^(fb_c w) * block 0
+    size_t lo = 0, hi = 0;            // generator index range resident here ([0, capacity) when unsharded)
+    int rank = 0, world = 1;
+    exchange_fn exchange = nullptr;
+    void *exchange_user = nullptr;
+    // fixed-base MSM: the table holds fb_windows blocks of npoints() records, block w = 2^(fb_c w) * block 0
     int fb_c = 0, fb_windows = 0;
-    size_t npoints() const { return 2 * capacity + 2; }
-    size_t off_G() const { return 0; }
-    size_t off_H() const { return capacity; }
-    size_t off_B() const { return 2 * capacity; }
-    size_t off_Bb() const { return 2 * capacity + 1; }
+    size_t local() const { return hi - lo; }
+    size_t npoints() const { return 2 * local() + 2; }
+    size_t off_G() const { return 0; }              // record of G_lo
+    size_t off_H() const { return local(); }        // record of H_lo
+    size_t off_B() const { return 2 * local(); }
+    size_t off_Bb() const { return 2 * local() + 1; }
 };
-int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out);
+int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank = 0, int world = 1, exchange_fn exchange = nullptr,
+                void *exchange_user = nullptr);
 void gens_destroy(Gens *g);
 
 // ---- proof ----------------------------------------------------------------------

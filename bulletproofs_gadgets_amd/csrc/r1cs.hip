@@ -581,16 +581,23 @@ struct GensExtra {
     aniels_rec *d_comb = nullptr;     // 2 x 64 x 8 comb table for B, B~
 };
 
-int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out) {
+int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, exchange_fn exchange, void *exchange_user) {
     if (!ctx || !out || capacity == 0 || capacity > ((size_t)1 << 26)) return BPG_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) return BPG_EINVAL;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     Gens *g = new Gens();
     g->ctx = ctx;
     g->capacity = capacity;
+    g->rank = rank;
+    g->world = world;
+    g->exchange = exchange;
+    g->exchange_user = exchange_user;
+    g->lo = capacity * (size_t)rank / (size_t)world;
+    g->hi = capacity * (size_t)(rank + 1) / (size_t)world;
     bpg_points *tbl = new bpg_points();
     tbl->ctx = ctx;
-    tbl->n = 2 * capacity + 2;
+    tbl->n = g->npoints();
     tbl->d_table = nullptr;
     g->fb_c = fixed_base_window(tbl->n);
     g->fb_windows = fixed_base_windows(g->fb_c);
@@ -602,16 +609,24 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out) {
         return BPG_ENOMEM;
     }
     g->table = tbl;
-    // BulletproofGens::new(capacity, 1): GeneratorsChain = SHAKE256("GeneratorsChain" | label), label = 'G'/'H' | u32le(0)
-    std::vector<uint8_t> stream(64 * capacity);
+    // BulletproofGens::new(capacity, 1): GeneratorsChain = SHAKE256("GeneratorsChain" | label), label = 'G'/'H' | u32le(0).
+    // The XOF stream is sequential: a rank squeezes past the generators it does not hold.
+    const size_t CH = (size_t)1 << 16;
+    std::vector<uint8_t> stream(64 * (capacity < CH ? capacity : CH));
     int rc;
     for (int which = 0; which < 2; which++) {
         KeccakSponge x = shake256();
         const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
         x.absorb("GeneratorsChain", 15);
         x.absorb(label, 5);
-        x.squeeze(stream.data(), stream.size());
-        if ((rc = table_write_uniform(ctx, tbl->d_table + (which ? g->off_H() : g->off_G()), stream.data(), capacity))) return rc;
+        for (size_t c0 = 0; c0 < g->hi; c0 += CH) {
+            const size_t c1 = c0 + CH < capacity ? c0 + CH : capacity;
+            x.squeeze(stream.data(), 64 * (c1 - c0));
+            const size_t a = c0 > g->lo ? c0 : g->lo, b = c1 < g->hi ? c1 : g->hi;
+            if (a >= b) continue;
+            aniels_rec *dst = tbl->d_table + (which ? g->off_H() : g->off_G()) + (a - g->lo);
+            if ((rc = table_write_uniform(ctx, dst, stream.data() + 64 * (a - c0), b - a))) return rc;
+        }
     }
     // PedersenGens::default(): B = ristretto basepoint, B_blinding = from_uniform_bytes(SHA3-512(compress(B)))
     ge Bp;
@@ -663,6 +678,59 @@ static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     (void)hipFree(d_s);
     (void)hipFree(d_o);
     return BPG_OK;
+}
+
+// =================================================================== MSMs over the (possibly sharded) generator table
+
+// generators [a, b) of G (which = 0) or H (which = 1) that are resident on this rank, as an MSM
+// segment; the scalar of generator i sits sc_base + (i - a) scalars into a target's row
+static msm_seg gen_seg(const Gens *g, int which, size_t a, size_t b, size_t sc_base) {
+    const size_t x = a > g->lo ? a : g->lo, y = b < g->hi ? b : g->hi;
+    const aniels_rec *tbl = g->table->d_table + (which ? g->off_H() : g->off_G());
+    if (x >= y) return msm_seg{tbl, 0, sc_base};
+    return msm_seg{tbl + (x - g->lo), y - x, sc_base + (x - a)};
+}
+// `count` records starting at B (first = 0) or B_blinding (first = 1): rank 0 alone adds these terms
+static msm_seg pedersen_seg(const Gens *g, int first, size_t count, size_t sc_off) {
+    return msm_seg{g->table->d_table + g->off_B() + first, g->rank == 0 ? count : 0, sc_off};
+}
+
+// all-gather this rank's partial sums (T x 128 B) and add them per target; every rank gets the
+// same T compressed points.  Unsharded: compress the single partial.
+static int finish_partials(Gens *g, const uint8_t *mine, int T, uint8_t *out32) {
+    if (g->world == 1) {
+        for (int t = 0; t < T; t++) {
+            int rc = combine_partials(mine + 128 * t, 1, out32 + 32 * t);
+            if (rc) return rc;
+        }
+        return BPG_OK;
+    }
+    const size_t bytes = (size_t)T * 128;
+    std::vector<uint8_t> all(bytes * g->world), one(128 * (size_t)g->world);
+    if (g->exchange(g->exchange_user, mine, bytes, all.data())) {
+        set_last_error_msg("partial-sum exchange failed");
+        return BPG_EDEVICE;
+    }
+    for (int t = 0; t < T; t++) {
+        for (int r = 0; r < g->world; r++) memcpy(&one[128 * r], &all[(size_t)r * bytes + 128 * t], 128);
+        int rc = combine_partials(one.data(), g->world, out32 + 32 * t);
+        if (rc) return rc;
+    }
+    return BPG_OK;
+}
+
+// One fixed-base MSM with T targets over this rank's part of the generator table.  Rows of
+// `stride` scalars each; segment k reads its scalars at segs[k].sc_off.
+static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, size_t stride, int T, uint8_t *out32) {
+    size_t n = 0;
+    for (int k = 0; k < nseg; k++) n += segs[k].len;
+    bpg_msm_job *job = nullptr;
+    int rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints()}, stride);
+    if (rc) return rc;
+    if (g->world == 1) return msm_wait(job, out32, false);
+    std::vector<uint8_t> mine((size_t)T * 128);
+    if ((rc = msm_wait(job, mine.data(), true))) return rc;
+    return finish_partials(g, mine.data(), T, out32);
 }
 
 // =================================================================== Prover
@@ -740,8 +808,6 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
-    const aniels_rec *tbl = gens_->table->d_table;
-    const msm_fixed_base fb{gens_->fb_c, gens_->npoints()};
     const size_t n = a_L_.size(), m = v_.size();
     const size_t np = next_pow2(n ? n : 1);
     if (gens_->capacity < np) return BPG_EGENS;
@@ -797,11 +863,9 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     // ---- A_I1, A_O1, S1: one 3-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
     {
-        msm_seg segs[3] = {{tbl + gens_->off_Bb(), 1}, {tbl + gens_->off_G(), n}, {tbl + gens_->off_H(), n}};
-        bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, segs, 3, d_rows, N1, 3, false, &job, fb))) return rc;
+        msm_seg segs[3] = {pedersen_seg(gens_, 1, 1, 0), gen_seg(gens_, 0, 0, n, 1), gen_seg(gens_, 1, 0, n, 1 + n)};
         uint8_t out[96];
-        if ((rc = msm_wait(job, out, false))) return rc;
+        if ((rc = gens_msm(gens_, segs, 3, d_rows, N1, 3, out))) return rc;
         memcpy(P.A_I1, out, 32);
         memcpy(P.A_O1, out + 32, 32);
         memcpy(P.S1, out + 64, 32);
@@ -892,11 +956,9 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
                            d_rowLR + NR + 2 * np);
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(hipStreamSynchronize(s));
-        msm_seg segs[3] = {{tbl + gens_->off_G(), np}, {tbl + gens_->off_H(), np}, {tbl + gens_->off_B(), 1}};
-        bpg_msm_job *job = nullptr;
-        if ((rc = msm_submit(ctx, segs, 3, d_rowLR, NR, 2, false, &job, fb))) return rc;
+        msm_seg segs[3] = {gen_seg(gens_, 0, 0, np, 0), gen_seg(gens_, 1, 0, np, np), pedersen_seg(gens_, 0, 1, 2 * np)};
         uint8_t out[64];
-        if ((rc = msm_wait(job, out, false))) return rc;
+        if ((rc = gens_msm(gens_, segs, 3, d_rowLR, NR, 2, out))) return rc;
         memcpy(&P.L_vec[32 * k], out, 32);
         memcpy(&P.R_vec[32 * k], out + 32, 32);
         tr_.append_point("L", out);
@@ -1071,16 +1133,33 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
     BPG_CHECK_HIP(hipMemcpyAsync(d_tail, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    const aniels_rec *tbl = gens->table->d_table;
-    msm_seg gh[2] = {{tbl + gens->off_G(), ng}, {tbl + gens->off_H(), nh}};
-    msm_seg rest[2] = {{tbl + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
+    // d_gh = [g[0..ng) | h[0..nh)]: each rank takes the generators it holds; rank 0 adds the rest
+    msm_seg gh[2] = {gen_seg(gens, 0, 0, ng, 0), gen_seg(gens, 1, 0, nh, ng)};
+    msm_seg rest[2] = {{gens->table->d_table + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
     bpg_msm_job *job_f = nullptr, *job_d = nullptr;
-    if ((rc = msm_submit(ctx, gh, 2, d_gh, ng + nh, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()}))) return rc;
-    if ((rc = msm_submit(ctx, rest, 2, d_tail, 2 + ndyn, 1, false, &job_d))) return rc;
+    if ((rc = msm_submit(ctx, gh, 2, d_gh, gh[0].len + gh[1].len, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()},
+                         ng + nh)))
+        return rc;
+    if (gens->rank == 0 && (rc = msm_submit(ctx, rest, 2, d_tail, 2 + ndyn, 1, false, &job_d))) return rc;
     uint8_t parts[256], out[32];
     if ((rc = msm_wait(job_f, parts, true))) return rc;
-    if ((rc = msm_wait(job_d, parts + 128, true))) return rc;
-    if ((rc = combine_partials(parts, 2, out))) return rc;
+    if (job_d) {
+        if ((rc = msm_wait(job_d, parts + 128, true))) return rc;
+    } else {
+        memset(parts + 128, 0, 128);          // identity: (0, 1, 1, 0)
+        parts[128 + 32] = 1;
+        parts[128 + 64] = 1;
+    }
+    if (gens->world == 1) {
+        if ((rc = combine_partials(parts, 2, out))) return rc;
+    } else {
+        std::vector<uint8_t> all(256 * (size_t)gens->world);
+        if (gens->exchange(gens->exchange_user, parts, 256, all.data())) {
+            set_last_error_msg("partial-sum exchange failed");
+            return BPG_EDEVICE;
+        }
+        if ((rc = combine_partials(all.data(), 2 * (size_t)gens->world, out))) return rc;
+    }
     uint8_t acc = 0;
     for (int i = 0; i < 32; i++) acc |= out[i];
     return acc ? BPG_EVERIFY : BPG_OK;

@@ -78,6 +78,15 @@ int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, b
     *out = new bpg_gens{g};
     return BPG_OK;
 }
+int bpg_gens_create_sharded(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, int rank, int world,
+                            bpg_exchange_fn exchange, void *exchange_user, bpg_gens **out) {
+    if (!out || party_capacity != 1) return BPG_EINVAL;
+    Gens *g = nullptr;
+    int rc = gens_create(ctx, gens_capacity, &g, rank, world, exchange, exchange_user);
+    if (rc) return rc;
+    *out = new bpg_gens{g};
+    return BPG_OK;
+}
 void bpg_gens_free(bpg_gens *g) {
     if (!g) return;
     gens_destroy(g->g);
@@ -86,16 +95,16 @@ void bpg_gens_free(bpg_gens *g) {
 size_t bpg_gens_capacity(const bpg_gens *g) { return g ? g->g->capacity : 0; }
 int bpg_gens_export(bpg_ctx *ctx, const bpg_gens *g, int which, size_t start, size_t n, uint8_t *out32) {
     if (!g) return BPG_EINVAL;
-    size_t base, lim;
-    switch (which) {
-        case 'G': base = g->g->off_G(); lim = g->g->capacity; break;
-        case 'H': base = g->g->off_H(); lim = g->g->capacity; break;
+    size_t base, first = 0, lim;
+    switch (which) {          // G / H: global generator indices; a sharded object holds [lo, hi) only
+        case 'G': base = g->g->off_G(); first = g->g->lo; lim = g->g->hi; break;
+        case 'H': base = g->g->off_H(); first = g->g->lo; lim = g->g->hi; break;
         case 'B': base = g->g->off_B(); lim = 1; break;
         case 'b': base = g->g->off_Bb(); lim = 1; break;
         default: return BPG_EINVAL;
     }
-    if (start + n > lim) return BPG_EINVAL;
-    return bpg_points_compress(ctx, g->g->table, base + start, n, out32);
+    if (start < first || start + n > lim) return BPG_EINVAL;
+    return bpg_points_compress(ctx, g->g->table, base + (start - first), n, out32);
 }
 
 // ---------------------------------------------------------------- prover

@@ -105,10 +105,31 @@ def _rng_cb(data):
 class BulletproofGens:
     """BulletproofGens::new(capacity, 1) + PedersenGens::default(), resident on the context's GPU."""
 
-    def __init__(self, ctx, gens_capacity, party_capacity=1):
+    def __init__(self, ctx, gens_capacity, party_capacity=1, shard=None):
+        """shard = (rank, world, all_gather): keep only this rank's generator range resident and
+        split every MSM of prove / verify by point range (bpg_gens_create_sharded).
+        all_gather(mine: bytes) -> bytes of every rank's `mine`, rank-major (e.g. make_all_gather(dist))."""
         self.ctx, self.gens_capacity = ctx, gens_capacity
         h = ctypes.c_void_p()
-        check(lib().bpg_gens_create(ctx._h, gens_capacity, party_capacity, ctypes.byref(h)))
+        if shard is None:
+            check(lib().bpg_gens_create(ctx._h, gens_capacity, party_capacity, ctypes.byref(h)))
+        else:
+            rank, world, all_gather = shard
+
+            def fn(_user, mine, nbytes, out):
+                try:
+                    res = all_gather(ctypes.string_at(mine, nbytes))
+                    if len(res) != nbytes * world:
+                        return 1
+                    ctypes.memmove(out, res, len(res))
+                    return 0
+                except Exception:      # noqa: BLE001  (must not unwind through the C ABI)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._exchange = _native.EXCHANGE_FN(fn)      # keep the trampoline alive
+            check(lib().bpg_gens_create_sharded(ctx._h, gens_capacity, party_capacity, rank, world, self._exchange, None,
+                                                ctypes.byref(h)))
         self._h = h.value
 
     def export(self, which, start=0, n=1):
@@ -272,6 +293,23 @@ def verify_batch(verifiers, proofs, bp_gens, external_rng=b""):
     return True
 
 
+def make_all_gather(dist, device=None):
+    """all_gather(mine) over torch.distributed for BulletproofGens(shard=...).  With device set
+    (e.g. "cuda") the 128-byte partial sums travel through device tensors, i.e. over RCCL / xGMI
+    with the "nccl" backend; device=None uses CPU tensors (gloo)."""
+    import torch
+
+    def all_gather(mine):
+        world = dist.get_world_size()
+        src = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        if device is not None:
+            src = src.to(device)
+        out = torch.empty(len(mine) * world, dtype=torch.uint8, device=src.device)
+        dist.all_gather_into_tensor(out, src)
+        return out.cpu().numpy().tobytes()
+    return all_gather
+
+
 def _xyzt(p):
     return _sc(p.X) + _sc(p.Y) + _sc(p.Z) + _sc(p.T)
 
@@ -396,5 +434,5 @@ def transcript_kat(label, msg_label, msg, challenge_label, n):
 
 
 __all__ = ["BpgError", "BulletproofGens", "LinearCombination", "LC", "Variable", "Prover", "Verifier", "Proof",
-           "VerificationError", "verify_batch", "SonnyEdwardsPointGadget", "SonnyRistrettoPointGadget", "binary_constrain_gadget",
+           "VerificationError", "verify_batch", "make_all_gather", "SonnyEdwardsPointGadget", "SonnyRistrettoPointGadget", "binary_constrain_gadget",
            "nonzero_gadget", "sk_knowledge_gadget", "transcript_kat"]

@@ -138,9 +138,22 @@ typedef void (*bpg_rng_fn)(void *user, uint8_t *out, size_t n);
  * The object is immutable once created: any number of host threads may prove and verify
  * against it at the same time, each on its own stream (one proof = one thread, as in the reference). */
 int bpg_gens_create(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, bpg_gens **out);
+/* Point-range sharding of ONE proof over the GPUs of a node (BASELINE config 4).  No counterpart in
+ * the reference (its prover is single-threaded).  Rank `rank` of `world` keeps the generators
+ * [cap*rank/world, cap*(rank+1)/world) of G and of H resident.  Every rank then runs the SAME Prover / Verifier
+ * calls on the SAME inputs (circuit, witness, external randomness); inside prove / verify each multiscalar
+ * multiplication runs over the rank's range only and `exchange` all-gathers the 128-byte partial sums
+ * (mine: `bytes` bytes in; all: world * bytes out, rank-major; return 0 on success), e.g. an RCCL all-gather.
+ * The partials are added on every rank, so all ranks see identical points, transcripts, proof bytes and
+ * verdicts -- the bytes an unsharded bpg_gens produces.  One proof at a time per sharded object
+ * (the exchange is a collective). */
+typedef int (*bpg_exchange_fn)(void *user, const uint8_t *mine, size_t bytes, uint8_t *all);
+int bpg_gens_create_sharded(bpg_ctx *ctx, size_t gens_capacity, size_t party_capacity, int rank, int world,
+                            bpg_exchange_fn exchange, void *exchange_user, bpg_gens **out);
 void bpg_gens_free(bpg_gens *gens);
 size_t bpg_gens_capacity(const bpg_gens *gens);
-/* compress generators: which = 'G' | 'H' (party-0 share), 'B' (pc_gens.B), 'b' (pc_gens.B_blinding) */
+/* compress generators: which = 'G' | 'H' (party-0 share; global indices, BPG_EINVAL outside a sharded object's range),
+ * 'B' (pc_gens.B), 'b' (pc_gens.B_blinding) */
 int bpg_gens_export(bpg_ctx *ctx, const bpg_gens *gens, int which, size_t start, size_t n, uint8_t *out32);
 
 /* Transcript::new(label) + Prover::new(&pc_gens, &mut transcript)   ref: tests/edwards_point.rs:25-28 */
