@@ -150,11 +150,72 @@ BPG_HD void sc_montreduce(sc &r, uint32_t t[16]) {
     for (int i = 0; i < 8; i++) r.v[i] = o[i];
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host form of a*b/R mod l: the same 256-bit values read as four 64-bit limbs, one
+// interleaved (CIOS) Montgomery pass with 64x64->128 products.  Circuit capture and the
+// transcript's scalar reductions run on the host; the limb layout in memory is unchanged.
+inline void sc_montmul_host64(sc &r, const sc &a, const sc &b) {
+    typedef unsigned __int128 u128;
+    static const uint64_t L[4] = {0x5812631a5cf5d3edULL, 0x14def9dea2f79cd6ULL, 0ULL, 0x1000000000000000ULL};
+    const uint64_t LF = 0xd2b51da312547e1bULL;          // -l^-1 mod 2^64
+    uint64_t A[4], B[4], t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    }
+    for (int i = 0; i < 4; i++) {
+        u128 acc;
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            acc = (u128)A[i] * B[j] + t[j] + carry;
+            t[j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        acc = (u128)t[4] + carry;
+        t[4] = (uint64_t)acc;
+        t[5] = (uint64_t)(acc >> 64);
+        const uint64_t m = t[0] * LF;
+        acc = (u128)m * L[0] + t[0];
+        carry = (uint64_t)(acc >> 64);
+        acc = (u128)m * L[1] + t[1] + carry;
+        t[0] = (uint64_t)acc;
+        carry = (uint64_t)(acc >> 64);
+        acc = (u128)t[2] + carry;                        // L[2] = 0
+        t[1] = (uint64_t)acc;
+        carry = (uint64_t)(acc >> 64);
+        acc = (u128)m * L[3] + t[3] + carry;
+        t[2] = (uint64_t)acc;
+        carry = (uint64_t)(acc >> 64);
+        acc = (u128)t[4] + carry;
+        t[3] = (uint64_t)acc;
+        t[4] = t[5] + (uint64_t)(acc >> 64);
+    }
+    // t < 2 l: one conditional subtraction
+    uint64_t u[4];
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)t[i] - L[i] - (uint64_t)bw;
+        u[i] = (uint64_t)d;
+        bw = (d >> 64) & 1;
+    }
+    const bool ge = t[4] != 0 || bw == 0;
+    for (int i = 0; i < 4; i++) {
+        const uint64_t w = ge ? u[i] : t[i];
+        r.v[2 * i] = (uint32_t)w;
+        r.v[2 * i + 1] = (uint32_t)(w >> 32);
+    }
+}
+#endif
+
 // a*b/R mod l
 BPG_HD void sc_montmul(sc &r, const sc &a, const sc &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    sc_montmul_host64(r, a, b);
+#else
     uint32_t t[16];
     mul_wide_8x8(t, a.v, b.v);
     sc_montreduce(r, t);
+#endif
 }
 BPG_HD void sc_to_mont(sc &r, const sc &a) { sc_montmul(r, a, sc_rr()); }
 BPG_HD void sc_from_mont(sc &r, const sc &a) { sc_montmul(r, a, sc_one()); }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include "../../bulletproofs_gadgets_amd/csrc/ge25519.h"
 #include "../../bulletproofs_gadgets_amd/csrc/sc25519.h"
+#include "../../bulletproofs_gadgets_amd/csrc/merlin.h"
 
 using namespace bpg;
 
@@ -57,5 +58,29 @@ int hh_group_ops(uint8_t *out_dbl_add, uint8_t *out_madd, uint8_t *out_msub, con
     ge_madd(r, p, n, true);
     ristretto_encode(out_msub, r);
     return 0;
+}
+
+// SHAKE256(in) -> out (host Keccak of the product: generator chain, transcript)
+void hh_shake256(uint8_t *out, size_t out_len, const uint8_t *in, size_t in_len) {
+    KeccakSponge x = shake256();
+    x.absorb(in, in_len);
+    x.squeeze(out, out_len);
+}
+// both compiled bodies of Keccak-f[1600] (baseline x86-64 and BMI) on the same state; 0 = equal.
+// which: 0 = generic only -> out, 1 = dispatching entry point -> out
+void hh_keccak_f(uint64_t *state, int which) {
+    if (which == 0) keccak_f1600_generic(state);
+    else keccak_f1600(state);
+}
+// TranscriptRng: Transcript::new(label).build_rng().rekey("v_blinding", witness32).finalize(ext32) -> n scalars
+void hh_transcript_rng(uint8_t *out, size_t n, const uint8_t *label, size_t label_len, const uint8_t *witness32, const uint8_t *ext32) {
+    Transcript tr(label, label_len);
+    TranscriptRng rng = tr.build_rng();
+    rng.rekey_with_witness_bytes("v_blinding", witness32, 32);
+    rng.finalize(ext32);
+    for (size_t i = 0; i < n; i++) {
+        sc s = rng.scalar();
+        sc_tobytes(out + 32 * i, s);
+    }
 }
 }

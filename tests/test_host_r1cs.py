@@ -69,3 +69,38 @@ def test_hard_errors_mirror_the_reference_panics():
     assert e.value.code == _native.EGADGET
     with pytest.raises(RuntimeError):            # panic!("Attempting to divide by 0 ..."), scalar.rs:13-15
         g.nonzero_gadget(g.LC.of(0), 0, v)
+
+
+def test_host_keccak_bodies_and_shake(host_hooks):
+    """the generated Keccak-f (baseline body and the BMI body picked at run time) against hashlib,
+    including squeezes that cross many rate boundaries (the generator chain reads megabytes)"""
+    import ctypes
+    import hashlib
+    import random
+    rnd = random.Random(3)
+    for n_in, n_out in ((0, 32), (5, 64), (135, 136), (136, 137), (137, 1000), (1000, 5000)):
+        msg = bytes(rnd.randrange(256) for _ in range(n_in))
+        out = ctypes.create_string_buffer(n_out)
+        host_hooks.hh_shake256(out, ctypes.c_size_t(n_out), msg, ctypes.c_size_t(n_in))
+        assert out.raw == hashlib.shake_256(msg).digest(n_out)
+    for _ in range(20):
+        st = [rnd.getrandbits(64) for _ in range(25)]
+        a = (ctypes.c_uint64 * 25)(*st)
+        b = (ctypes.c_uint64 * 25)(*st)
+        host_hooks.hh_keccak_f(a, 0)
+        host_hooks.hh_keccak_f(b, 1)
+        assert list(a) == list(b)
+
+
+def test_host_transcript_rng_matches_oracle(host_hooks, oracle):
+    """the prover's blinding stream (merlin TranscriptRng over STROBE) equals the oracle's, scalar for scalar"""
+    import ctypes
+    from oracle import r1cs as R
+    n = 300                      # crosses the STROBE rate many times
+    wit, ext = bytes(range(31)) + b"\x05", bytes(range(100, 132))      # witness below l
+    out = ctypes.create_string_buffer(32 * n)
+    host_hooks.hh_transcript_rng(out, ctypes.c_size_t(n), b"rng-test", ctypes.c_size_t(8), wit, ext)
+    tr = R.Transcript(oracle, b"rng-test")
+    rng = tr.build_rng([int.from_bytes(wit, "little")], ext)          # rekeys with label "v_blinding"
+    want = b"".join(x.to_bytes(32, "little") for x in rng.scalars(n))
+    assert out.raw == want
