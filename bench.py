@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
     ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "16")))
     ap.add_argument("--proofs-per-thread", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "2")),
+                    help="MSM jobs submitted before the oldest is waited for (each on its own stream)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,7 +205,7 @@ def main():
         inflight, out = [], None
         for _ in range(steps):
             inflight.append(ctx.msm_submit(pts, d_sc.ptr, n))
-            if len(inflight) == 2:
+            if len(inflight) == args.in_flight:
                 out = finish(inflight.pop(0))
                 if acc_us is not None:
                     acc_us.append(ctx.msm_last_kernel_us()[0])
@@ -262,7 +264,7 @@ def main():
             "data": "synthetic (SHAKE256 uniform points and scalars, seed bpg-bench-v1)",
             "config": {"workload": "raw Ristretto255 MSM, 2^%d points per GPU, point-range sharded (BASELINE configs[1])" % args.logn,
                        "points_per_gpu": n, "window_bits": plan["window_bits"], "windows": plan["windows"],
-                       "in_flight": 2, "table_build_s": round(table_s, 4), "result": result.hex()},
+                       "in_flight": args.in_flight, "table_build_s": round(table_s, 4), "result": result.hex()},
             "roofline": {"bound": "valu_int32 (v_mad_u64_u32 issue)", "kernel": "k_accumulate",
                          "achieved": achieved, "peak": VMAD_PEAK_GMACS, "unit": "GMAC/s", "frac": achieved / VMAD_PEAK_GMACS,
                          "kernel_avg_us": acc, "algorithmic_mac_per_point": MAC_PER_POINT_ACCUMULATE,

@@ -387,16 +387,66 @@ __device__ __forceinline__ uint32_t find_bucket(const level_ref &lv, uint32_t t,
     return g;
 }
 
-// THE hot kernel.  Thread t owns segment `rank` (S0 entries) of bucket g and sums
-// it with 7M mixed additions.  Integer-VALU bound (v_mad_u64_u32 chains).
+// Thread -> bucket maps of the accumulate pass (level 0) and of the first merge pass (level 1):
+// map[off(g) + r] = g for every thread r of bucket g.  A thread of those passes then finds its
+// bucket with ONE coalesced load instead of an 18-step binary search, i.e. a chain of 18
+// dependent memory round trips that every wave of a freshly launched round walked at the same
+// time while its SIMD sat idle.  One thread per bucket; buckets with more than 32 threads
+// (skewed digits) are finished by the whole wave, 64 entries per step.
+__global__ void __launch_bounds__(256) k_segmap(const uint32_t *__restrict__ counts, level_ref lv0, level_ref lv1,
+                                                uint32_t *__restrict__ map0, uint32_t *__restrict__ map1, uint32_t ne, int ls0,
+                                                int ls1) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t cnt = g < ne ? counts[g] : 0u;
+#pragma unroll
+    for (int level = 0; level < 2; level++) {
+        if (level == 1 && !map1) break;
+        const level_ref &lv = level ? lv1 : lv0;
+        uint32_t *map = level ? map1 : map0;
+        const uint32_t ns = pass_threads(cnt, level, ls0, ls1);
+        const uint32_t off = ns ? lv.local[g] + lv.base[g >> 10] : 0u;
+        const uint32_t first = ns < 32u ? ns : 32u;
+        for (uint32_t r = 0; r < first; r++) map[off + r] = g;
+        uint64_t big = __ballot(ns > 32u);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bg = __shfl(g, src, 64), boff = __shfl(off, src, 64), bns = __shfl(ns, src, 64);
+            for (uint32_t r = 32u + lane; r < bns; r += 64u) map[boff + r] = bg;
+        }
+    }
+}
+
+// record of scalar index i.  The four segment bases are wave-uniform kernel arguments: they are
+// pinned in SGPRs so that the choice is three v_cndmask pairs -- left alone, the compiler turns the
+// select chain into an indexed load from the kernarg segment, i.e. one more dependent memory
+// round trip in front of every point gather.
+template <bool MULTI>
+__device__ __forceinline__ const aniels_rec *record_of(const seg_map &m, uint32_t i) {
+    uint64_t b0 = (uint64_t)m.base[0];
+    if (MULTI) {
+        uint64_t b1 = (uint64_t)m.base[1], b2 = (uint64_t)m.base[2], b3 = (uint64_t)m.base[3];
+        asm volatile("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
+        b0 = i >= m.len[0] ? b1 : b0;
+        b0 = i >= m.len[1] ? b2 : b0;
+        b0 = i >= m.len[2] ? b3 : b0;
+    }
+    return (const aniels_rec *)b0 + i;
+}
+
+// THE hot kernel.  Thread t owns segment `rank` (S0 entries) of bucket g = map0[t] and sums
+// it with 7M mixed additions.  VALU-issue bound: ~1300 integer instructions per addition,
+// 504 of them v_mad_u64_u32.
+template <bool MULTI>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ counts, level_ref ent, level_ref lv0,
-                                                    ge_rec *__restrict__ parts, uint32_t nblk, uint32_t ne, int ls0,
-                                                    seg_map map, uint32_t wstride) {
+                                                    const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts,
+                                                    uint32_t nblk, int ls0, seg_map map, uint32_t wstride) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= lv0.base[nblk]) return;
-    uint32_t rank;
-    uint32_t g = find_bucket(lv0, t, nblk, ne, rank);
+    const uint32_t g = map0[t];
+    const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
     uint32_t cnt = counts[g];
     uint32_t off = ent.local[g] + ent.base[g >> 10];
     uint32_t lo = rank << ls0, hi = lo + (1u << ls0);
@@ -410,20 +460,27 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
         // of point i (2^(c w) P_i) lives wstride records further per window
         const uint32_t idx = wstride ? (en & 0x03ffffffu) : (en & 0x7fffffffu);
         const uint32_t win = wstride ? ((en >> 26) & 31u) : 0u;   // fixed-base tables have <= 28 windows
-        load_aniels(q, map_record(map, idx) + (size_t)win * wstride);
+        load_aniels(q, record_of<MULTI>(map, idx) + (size_t)win * wstride);
         ge_madd(acc, acc, q, (en >> 31) != 0);
     }
     store_ge(parts + t, acc);
 }
 
 // reduction pass `level` (>= 1): thread t merges up to S1 partials of level-1 of its bucket
+// (map != nullptr: thread -> bucket map of this pass, see k_segmap; else binary search)
 __global__ void __launch_bounds__(256) k_reduce(const uint32_t *__restrict__ counts, level_ref prev, level_ref cur,
-                                                const ge_rec *__restrict__ parts_in, ge_rec *__restrict__ parts_out,
-                                                uint32_t nblk, uint32_t ne, int level, int ls0, int ls1) {
+                                                const uint32_t *__restrict__ map, const ge_rec *__restrict__ parts_in,
+                                                ge_rec *__restrict__ parts_out, uint32_t nblk, uint32_t ne, int level, int ls0,
+                                                int ls1) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= cur.base[nblk]) return;
-    uint32_t rank;
-    uint32_t g = find_bucket(cur, t, nblk, ne, rank);
+    uint32_t rank, g;
+    if (map) {
+        g = map[t];
+        rank = t - (cur.local[g] + cur.base[g >> 10]);
+    } else {
+        g = find_bucket(cur, t, nblk, ne, rank);
+    }
     uint32_t kprev = seg_count(counts[g], level - 1, ls0, ls1);
     uint32_t in0 = prev.local[g] + prev.base[g >> 10];
     uint32_t lo = rank << ls1, hi = lo + (1u << ls1);
@@ -696,7 +753,9 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     const size_t lvl_words = NE + nblk + 1;                // local[NE] | base[nblk + 1]
     if ((rc = grow((void **)&j->d_digits, &j->cap_digits, M * sizeof(int16_t)))) return rc;
     if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
-    if ((rc = grow((void **)&j->d_counts, &j->cap_counts, (2 * NE + (size_t)(nlevels + 1) * lvl_words + 16) * sizeof(uint32_t))))
+    const size_t map_words = cap_lv[0] + (nlevels > 1 ? cap_lv[1] : 0);
+    if ((rc = grow((void **)&j->d_counts, &j->cap_counts,
+                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 16) * sizeof(uint32_t))))
         return rc;
     if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
     if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.Wb * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
@@ -730,14 +789,21 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         L.lv[r] = level_ref{lv_local(r + 1), lv_tot(r + 1)};
         L.parts[r] = j->d_partials + part_off[r];
     }
+    // thread -> bucket maps of levels 0 and 1 (level 1 only exists when nlevels > 1)
+    uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
+    hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
+                       map0, map1, (uint32_t)NE, pl.ls0, pl.ls1);
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries,
-                       counts, ent, L.lv[0], j->d_partials + part_off[0], (uint32_t)nblk, (uint32_t)NE, pl.ls0, map,
-                       (uint32_t)fb.wstride);
+    if (nseg > 1)
+        hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
+                           ent, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
+    else
+        hipLaunchKernelGGL((k_accumulate<false>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
+                           ent, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
     for (int r = 1; r < nlevels; r++)
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r],
-                           j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
+                           r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr, j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
                            pl.ls0, pl.ls1);
     ge_rec *a_out = pl.nchunks == 1 ? j->d_out : j->d_chunk;
     hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #include "../bulletproofs_gadgets_amd/csrc/ge25519.h"
@@ -25,16 +26,23 @@ using namespace bpg;
 
 constexpr int ITERS = 512;
 
-// 8 independent mad chains per lane
+// 8 independent mad chains per lane, each with its own multiplicands (one v_mad_u64_u32 per
+// chain step: with shared multiplicands the compiler computes the product once and adds it
+// eight times, which is what an earlier version of this test measured by mistake)
 __global__ void __launch_bounds__(256) k_mad64(uint64_t *out, uint32_t a, uint32_t b) {
     uint64_t acc[8];
-    uint32_t x = a + threadIdx.x, y = b + blockIdx.x;
+    uint32_t x[8], y[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = k + threadIdx.x;
+    for (int k = 0; k < 8; k++) {
+        acc[k] = k + threadIdx.x;
+        x[k] = a * (2 * k + 3) + threadIdx.x;
+        y[k] = b * (2 * k + 5) + blockIdx.x;
+    }
     for (int i = 0; i < ITERS; i++) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] = (uint64_t)x * y + acc[k];
-        x ^= (uint32_t)acc[0];   // keep operands live / varying
+        for (int k = 0; k < 8; k++) acc[k] = (uint64_t)x[k] * y[k] + acc[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(x[k]));      // opaque: no hoisting of x*y
     }
     uint64_t s = 0;
 #pragma unroll
@@ -150,6 +158,34 @@ __global__ void __launch_bounds__(256) k_madd(fe *out, const fe *in) {
     out[i + 3] = acc.T;
 }
 
+// ge_madd loop with in-kernel stamps: cycles (s_memtime) and 100 MHz ticks (s_memrealtime) per wave,
+// written to a buffer nothing else reads.  Gives cycles per mixed addition at the launch's occupancy
+// and the clock the chip holds under this load (MI355X_MICROARCH.md, DVFS give-back item 6).
+__global__ void __launch_bounds__(256) k_madd_stamped(fe *out, const fe *in, uint64_t *stamps, int iters) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    ge acc;
+    ge_identity(acc);
+    ge_aniels q;
+    q.YpX = in[i];
+    q.YmX = in[i + 1];
+    q.T2d = in[i + 2];
+    uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < iters; k++) {
+        ge_madd(acc, acc, q, (k & 1) != 0);
+        q.T2d.v[0] ^= acc.X.v[0];          // keep the operand varying
+    }
+    uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[i] = acc.X;
+    out[i + 1] = acc.Y;
+    out[i + 2] = acc.Z;
+    out[i + 3] = acc.T;
+    if ((threadIdx.x & 63) == 0) {
+        size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = c1 - c0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 5) {
     hipEvent_t a, b;
@@ -208,6 +244,40 @@ int main(int argc, char **argv) {
     ms = time_ms([&] { hipLaunchKernelGGL(k_fesq, dim3(blocks), dim3(256), 0, 0, (fe *)buf, (const fe *)in); });
     printf(" \"fe_sq_G\": %.2f,\n", lanes * ITERS / ms / 1e6);
     ms = time_ms([&] { hipLaunchKernelGGL(k_madd, dim3(blocks), dim3(256), 0, 0, (fe *)buf, (const fe *)in); });
-    printf(" \"ge_madd_G\": %.3f\n}\n", lanes * (ITERS / 8) / ms / 1e6);
+    printf(" \"ge_madd_G\": %.3f,\n", lanes * (ITERS / 8) / ms / 1e6);
+    // stamped ge_madd loop at 1, 2, 4 and all resident waves per SIMD (blocks of 4 waves: one wave per SIMD each)
+    {
+        const int iters = 2000;
+        uint64_t *stamps;
+        CHECK(hipMalloc((void **)&stamps, (size_t)blocks * 4 * 16));
+        std::vector<uint64_t> hs((size_t)blocks * 8);
+        printf(" \"ge_madd_stamped\": [");
+        const int bpcs[4] = {1, 2, 4, blocks_per_cu};
+        for (int v = 0; v < 4; v++) {
+            int nb = cus * bpcs[v];
+            for (int rep = 0; rep < 3; rep++)
+                hipLaunchKernelGGL(k_madd_stamped, dim3(nb), dim3(256), 0, 0, (fe *)buf, (const fe *)in, stamps, iters);
+            hipEvent_t a, b;
+            CHECK(hipEventCreate(&a));
+            CHECK(hipEventCreate(&b));
+            CHECK(hipEventRecord(a));
+            hipLaunchKernelGGL(k_madd_stamped, dim3(nb), dim3(256), 0, 0, (fe *)buf, (const fe *)in, stamps, iters);
+            CHECK(hipEventRecord(b));
+            CHECK(hipEventSynchronize(b));
+            float ems;
+            CHECK(hipEventElapsedTime(&ems, a, b));
+            CHECK(hipMemcpy(hs.data(), stamps, (size_t)nb * 4 * 16, hipMemcpyDeviceToHost));
+            std::vector<double> cyc, clk;
+            for (int w = 0; w < nb * 4; w++) {
+                cyc.push_back((double)hs[2 * w] / iters);
+                clk.push_back((double)hs[2 * w] / (double)hs[2 * w + 1] * 100.0);
+            }
+            std::sort(cyc.begin(), cyc.end());
+            std::sort(clk.begin(), clk.end());
+            printf("%s{\"waves_per_simd\": %d, \"cycles_per_madd_per_wave\": %.0f, \"clock_mhz\": %.0f, \"madd_G\": %.2f}",
+                   v ? ", " : "", bpcs[v], cyc[cyc.size() / 2], clk[clk.size() / 2], (double)nb * 256 * iters / ems / 1e6);
+        }
+        printf("]\n}\n");
+    }
     return 0;
 }
