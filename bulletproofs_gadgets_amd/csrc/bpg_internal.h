@@ -53,6 +53,8 @@ struct msm_plan {
     int chunk;        // buckets per tail-A block = min(256, NB)
     int nchunks;      // NB / chunk
     int outs;         // points per (target, window) = c  (total + c-1 bit sums)
+    int nbin;         // bins per bucket set in the two-level sort (NB = nbin << lowshift)
+    int lowshift;     // log2(buckets per bin)
 };
 struct msm_tuning {
     int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
@@ -97,6 +99,7 @@ struct bpg_msm_job {
     bpg::ge_rec *d_out = nullptr;     size_t cap_out = 0;
     bpg::ge_rec *h_out = nullptr;     size_t cap_hout = 0;      // pinned host
     void *d_stage = nullptr;          size_t cap_stage = 0;     // scalars staged from the host
+    void *d_tmp = nullptr;            size_t cap_tmp = 0;       // bin-partitioned entries (level 1 of the sort)
     std::atomic<bool> busy{false};
 };
 

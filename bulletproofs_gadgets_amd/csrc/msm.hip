@@ -10,9 +10,11 @@
 // Pipeline for n scalars x T targets, window c bits, W = 255/c+1 windows,
 // NB = 2^(c-1) signed buckets per window:
 //   k_digits      scalar -> W signed digits (int16), [target][window][i] layout   (HBM stream)
-//   k_hist        per (tile, window, target): LDS histogram, coalesced flush       (LDS atomics)
-//   k_scan_a/b    exclusive scan of bucket counts
-//   k_scatter     LDS cursors -> bucket-sorted entry list (point index | sign)
+//   k_bin_hist / k_bin_scan / k_bin_scatter / k_bin_sort
+//                 two-level bucket sort of the entries (point index | sign): bins, then buckets
+//                 inside a bin with LDS cursors; yields bucket counts and entry offsets
+//   k_scan_a/b    exclusive scans: thread offsets of every pass
+//   k_segmap      thread -> bucket maps of the accumulate pass and the first merge pass
 //   k_accumulate  P threads per bucket: mixed additions (7M each)                  (VALU int32: the hot kernel)
 //   k_tail_a/b    merge the P partials, then an LDS binary tree that yields, per
 //                 window, the bucket total and the c-1 "bit j of bucket index"
@@ -194,26 +196,185 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
     }
 }
 
-// per (tile, window, target): LDS histogram of |digit|, flushed with coalesced atomics
-// (fixed-base mode, `shared` != 0: all windows of a target count into ONE bucket set)
-__global__ void __launch_bounds__(512) k_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ counts, size_t n,
-                                              int W, int NB, int tile, int shared) {
+// ---- bucket sort of the non-zero digits, in two levels -------------------------------------
+// A bucket set (one per (target, window); fixed-base mode: one per target, shared by all its
+// windows) has NB = NBIN * LOWN buckets.  Level 1 splits the entries of a set into NBIN bins by
+// the high bits of the bucket number: a block owns one (tile, window, target), keeps its bin
+// cursors in LDS and claims a run in each bin's region with one global atomic, so its stores
+// land in NBIN runs of ~tile/NBIN entries.  Level 2 gives each bin to one block, which counts
+// the LOWN buckets of the bin in LDS, writes counts and entry offsets of its buckets, and
+// places the entries: all its stores fall into the bin's own region (tens of KB), which the
+// L2 holds until every line is complete.  (A one-level scatter to 8192 buckets wrote 16-byte
+// runs all over a 75 MB array: measured 7.7x write amplification and 4.7 M returning atomics.)
+
+constexpr int SORT_U = 8;
+
+// bin histogram: bin_counts[bset * NBIN + bin] += entries of this (tile, window, target)
+__global__ void __launch_bounds__(512) k_bin_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ bin_counts, size_t n,
+                                                  int W, int NBIN, int lowshift, int tile, int shared) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, t = blockIdx.z;
     const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
     const int16_t *dg = digits + base * n;
-    for (int b = threadIdx.x; b < NB; b += blockDim.x) lds[b] = 0;
+    for (int b = threadIdx.x; b < NBIN; b += blockDim.x) lds[b] = 0;
     __syncthreads();
     size_t start = (size_t)blockIdx.x * tile, end = start + tile < n ? start + tile : n;
-    for (size_t i = start + threadIdx.x; i < end; i += blockDim.x) {
-        int d = dg[i];
-        if (d != 0) atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
+    // SORT_U independent loads per step: these loops are bound by load latency, not by bytes
+    for (size_t i0 = start + threadIdx.x; i0 < end; i0 += (size_t)blockDim.x * SORT_U) {
+        int d[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            d[u] = i < end ? dg[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++)
+            if (d[u] != 0) atomicAdd(&lds[((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift], 1u);
     }
     __syncthreads();
-    uint32_t *gc = counts + bset * NB;
-    for (int b = threadIdx.x; b < NB; b += blockDim.x) {
+    uint32_t *gc = bin_counts + bset * NBIN;
+    for (int b = threadIdx.x; b < NBIN; b += blockDim.x) {
         uint32_t c = lds[b];
         if (c) atomicAdd(&gc[b], c);
+    }
+}
+
+// exclusive scan of the bin counts (one block; at most a few thousand bins)
+__global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t *__restrict__ bin_counts, uint32_t *__restrict__ bin_off, uint32_t nbt) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t running;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t start = 0; start < nbt; start += 1024) {
+        uint32_t i = start + threadIdx.x;
+        uint32_t mine = i < nbt ? bin_counts[i] : 0u;
+        uint32_t x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t wbase = running;
+        for (int k = 0; k < wave; k++) wbase += wsum[k];
+        if (i < nbt) bin_off[i] = wbase + x - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) running = wbase + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bin_off[nbt] = running;
+}
+
+// level 1: entries -> bins.  tmp[pos] = (entry, bucket number within the bin); entry = scalar
+// index | sign << 31 (fixed-base mode: also the window << 26, i.e. which block of the shifted
+// table the point comes from)
+__global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ bin_off,
+                                                     uint32_t *__restrict__ bin_fill, uint2 *__restrict__ tmp, size_t n, int W,
+                                                     int NBIN, int lowshift, int tile, int shared) {
+    extern __shared__ uint32_t lds[];
+    const int w = blockIdx.y, t = blockIdx.z;
+    const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
+    const uint32_t wtag = shared ? (uint32_t)w << 26 : 0u;
+    const uint32_t lowmask = (1u << lowshift) - 1u;
+    const int16_t *dg = digits + base * n;
+    for (int b = threadIdx.x; b < NBIN; b += blockDim.x) lds[b] = 0;
+    __syncthreads();
+    size_t start = (size_t)blockIdx.x * tile, end = start + tile < n ? start + tile : n;
+    for (size_t i0 = start + threadIdx.x; i0 < end; i0 += (size_t)blockDim.x * SORT_U) {
+        int d[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            d[u] = i < end ? dg[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++)
+            if (d[u] != 0) atomicAdd(&lds[((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBIN; b += blockDim.x) {
+        uint32_t c = lds[b];
+        if (c) {
+            size_t gb = bset * NBIN + b;
+            lds[b] = bin_off[gb] + atomicAdd(&bin_fill[gb], c);
+        }
+    }
+    __syncthreads();
+    for (size_t i0 = start + threadIdx.x; i0 < end; i0 += (size_t)blockDim.x * SORT_U) {
+        int d[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            d[u] = i < end ? dg[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            if (d[u] != 0) {
+                const size_t i = i0 + (size_t)u * blockDim.x;
+                const uint32_t bk = (uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1u;
+                const uint32_t pos = atomicAdd(&lds[bk >> lowshift], 1u);
+                tmp[pos] = make_uint2((uint32_t)i | wtag | (d[u] < 0 ? 0x80000000u : 0u), bk & lowmask);
+            }
+        }
+    }
+}
+
+// level 2: one block per bin.  counts[g], ent_off[g] for the bin's LOWN buckets; entries sorted by bucket.
+__global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ bin_off, const uint2 *__restrict__ tmp,
+                                                  uint32_t *__restrict__ counts, uint32_t *__restrict__ ent_off,
+                                                  uint32_t *__restrict__ entries, int LOWN) {
+    __shared__ uint32_t cnt[256], cur[256];
+    __shared__ uint32_t wsum[4];
+    const uint32_t bin = blockIdx.x;
+    const uint32_t lo = bin_off[bin], hi = bin_off[bin + 1];
+    const int tid = threadIdx.x;
+    cnt[tid] = 0;
+    __syncthreads();
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 256u * SORT_U) {
+        uint32_t b[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            const uint32_t i = i0 + 256u * u;
+            b[u] = i < hi ? tmp[i].y : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++)
+            if (b[u] != 0xffffffffu) atomicAdd(&cnt[b[u]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..256) (LOWN <= 256; the rest is zero)
+    const uint32_t mine = cnt[tid];
+    uint32_t x = mine;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int k = 0; k < wave; k++) wbase += wsum[k];
+    const uint32_t off = lo + wbase + x - mine;
+    cur[tid] = off;
+    if (tid < LOWN) {
+        const size_t g = (size_t)bin * LOWN + tid;
+        counts[g] = mine;
+        ent_off[g] = off;
+    }
+    __syncthreads();
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 256u * SORT_U) {
+        uint2 it[SORT_U];
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++) {
+            const uint32_t i = i0 + 256u * u;
+            it[u] = i < hi ? tmp[i] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int u = 0; u < SORT_U; u++)
+            if (it[u].y != 0xffffffffu) entries[atomicAdd(&cur[it[u].y], 1u)] = it[u].x;
     }
 }
 
@@ -313,41 +474,6 @@ __global__ void __launch_bounds__(1024) k_scan_b(uint32_t *__restrict__ lvl, siz
     if (threadIdx.x == 0) totals[nblk] = running;
 }
 
-// bucket-sorted entry list.  entries[pos] = scalar index | sign << 31, and in fixed-base
-// mode also the window (which block of the shifted table the point comes from) << 26
-__global__ void __launch_bounds__(512) k_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ local,
-                                                 const uint32_t *__restrict__ blockbase, uint32_t *__restrict__ fill,
-                                                 uint32_t *__restrict__ entries, size_t n, int W, int NB, int tile, int shared) {
-    extern __shared__ uint32_t lds[];
-    const int w = blockIdx.y, t = blockIdx.z;
-    const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
-    const uint32_t wtag = shared ? (uint32_t)w << 26 : 0u;
-    const int16_t *dg = digits + base * n;
-    for (int b = threadIdx.x; b < NB; b += blockDim.x) lds[b] = 0;
-    __syncthreads();
-    size_t start = (size_t)blockIdx.x * tile, end = start + tile < n ? start + tile : n;
-    for (size_t i = start + threadIdx.x; i < end; i += blockDim.x) {
-        int d = dg[i];
-        if (d != 0) atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < NB; b += blockDim.x) {
-        uint32_t c = lds[b];
-        if (c) {
-            size_t g = bset * NB + b;
-            lds[b] = local[g] + blockbase[g >> 10] + atomicAdd(&fill[g], c);
-        }
-    }
-    __syncthreads();
-    for (size_t i = start + threadIdx.x; i < end; i += blockDim.x) {
-        int d = dg[i];
-        if (d != 0) {
-            uint32_t pos = atomicAdd(&lds[(d < 0 ? -d : d) - 1], 1u);
-            entries[pos] = (uint32_t)i | wtag | (d < 0 ? 0x80000000u : 0u);
-        }
-    }
-}
-
 struct seg_map {
     uint32_t len[4];             // cumulative ends of the segments in scalar-index space
     const aniels_rec *base[4];   // record of scalar index i in segment k is base[k][i]  (base pre-shifted by -len[k-1])
@@ -440,7 +566,8 @@ __device__ __forceinline__ const aniels_rec *record_of(const seg_map &m, uint32_
 // 504 of them v_mad_u64_u32.
 template <bool MULTI>
 __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__ entries,
-                                                    const uint32_t *__restrict__ counts, level_ref ent, level_ref lv0,
+                                                    const uint32_t *__restrict__ counts,
+                                                    const uint32_t *__restrict__ ent_off, level_ref lv0,
                                                     const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts,
                                                     uint32_t nblk, int ls0, seg_map map, uint32_t wstride) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -448,7 +575,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
     const uint32_t g = map0[t];
     const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
     uint32_t cnt = counts[g];
-    uint32_t off = ent.local[g] + ent.base[g >> 10];
+    uint32_t off = ent_off[g];
     uint32_t lo = rank << ls0, hi = lo + (1u << ls0);
     hi = hi < cnt ? hi : cnt;
     ge acc;
@@ -519,7 +646,7 @@ __device__ __forceinline__ void bucket_sum(ge &acc, const levels_dev &L, const u
 
 // tail A: one block per chunk of `chunk` buckets of one (target, window): bit tree
 // over the bucket index; writes log2(chunk)+1 points per chunk.
-__global__ void __launch_bounds__(256) k_tail_a(levels_dev L, const uint32_t *__restrict__ counts, ge_rec *__restrict__ out,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_tail_a(levels_dev L, const uint32_t *__restrict__ counts, ge_rec *__restrict__ out,
                                                 int NB, int chunk, int logchunk, int W, int ls0, int ls1) {
     extern __shared__ uint32_t lds[];
     const int cidx = blockIdx.x, w = blockIdx.y, t = blockIdx.z;
@@ -618,6 +745,16 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c) {
     if (pl.ntiles < 1) pl.ntiles = 1;
     pl.n = n;
     pl.T = T;
+    // bins of the two-level sort: ~8k entries each, at most 256 buckets per bin
+    {
+        const size_t items = (fixed_c ? (size_t)pl.W : (size_t)1) * n;
+        int nbin = 1;
+        while (nbin < pl.NB && items / (size_t)nbin > 8192) nbin <<= 1;
+        while (pl.NB / nbin > 256) nbin <<= 1;
+        pl.nbin = nbin;
+        pl.lowshift = 0;
+        while ((nbin << pl.lowshift) < pl.NB) pl.lowshift++;
+    }
     pl.chunk = pl.NB < 256 ? pl.NB : 256;
     pl.nchunks = pl.NB / pl.chunk;
     pl.outs = c;
@@ -675,6 +812,7 @@ void msm_job_destroy(bpg_msm_job *j) {
     (void)hipFree(j->d_chunk);
     (void)hipFree(j->d_out);
     (void)hipFree(j->d_stage);
+    (void)hipFree(j->d_tmp);
     if (j->h_out) (void)hipHostFree(j->h_out);
     for (auto &e : j->ev)
         if (e) (void)hipEventDestroy(e);
@@ -754,9 +892,11 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if ((rc = grow((void **)&j->d_digits, &j->cap_digits, M * sizeof(int16_t)))) return rc;
     if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
     const size_t map_words = cap_lv[0] + (nlevels > 1 ? cap_lv[1] : 0);
+    const size_t NBT = (size_t)T * pl.Wb * pl.nbin;        // bins
     if ((rc = grow((void **)&j->d_counts, &j->cap_counts,
-                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 16) * sizeof(uint32_t))))
+                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 3 * NBT + 16) * sizeof(uint32_t))))
         return rc;
+    if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, M * sizeof(uint2) + 64))) return rc;    // level-1 output: (entry, bucket in bin)
     if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
     if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.Wb * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
     const uint32_t *d_sc = (const uint32_t *)d_scalars;
@@ -765,24 +905,31 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         BPG_CHECK_HIP(hipMemcpyAsync(j->d_stage, d_scalars, (size_t)T * n * 32, hipMemcpyHostToDevice, s));
         d_sc = (const uint32_t *)j->d_stage;
     }
-    uint32_t *counts = j->d_counts, *fill = counts + NE;
-    uint32_t *lvl_base = fill + NE;                        // level -1 (entry offsets), then levels 0..R
+    uint32_t *counts = j->d_counts, *ent_off = counts + NE;
+    uint32_t *lvl_base = ent_off + NE;                     // level -1 (unused), then levels 0..R
     auto lv_local = [&](int idx) { return lvl_base + (size_t)idx * lvl_words; };
     auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
-    BPG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * NE * sizeof(uint32_t), s));
 
     const int shared = fb.c ? 1 : 0;
     dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap);
+    // two-level bucket sort: bins (high bucket bits), then buckets inside each bin
+    uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
+    uint32_t *bin_counts = map0 + map_words, *bin_fill = bin_counts + NBT, *bin_off = bin_fill + NBT;
+    uint2 *tmp = (uint2 *)j->d_tmp;
+    BPG_CHECK_HIP(hipMemsetAsync(bin_counts, 0, 2 * NBT * sizeof(uint32_t), s));
     dim3 tgrid(pl.ntiles, pl.W, T);
-    size_t hist_lds = (size_t)pl.NB * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_hist, tgrid, dim3(512), hist_lds, s, j->d_digits, counts, n, pl.W, pl.NB, pl.tile, shared);
-    // entry offsets (level -1) and the thread offsets of every pass (levels 0..R), two launches
+    const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile,
+                       shared);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, (uint32_t)NBT);
+    hipLaunchKernelGGL(k_bin_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, pl.W,
+                       pl.nbin, pl.lowshift, pl.tile, shared);
+    hipLaunchKernelGGL(k_bin_sort, dim3((unsigned)NBT), dim3(256), 0, s, bin_off, tmp, counts, ent_off,
+                       j->d_entries, pl.NB / pl.nbin);
+    // thread offsets of every pass (levels 0..R), two launches
     hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, pl.ls0,
                        pl.ls1);
     hipLaunchKernelGGL(k_scan_b, dim3(nlevels + 1), dim3(1024), 0, s, lvl_base, lvl_words, NE, nblk);
-    hipLaunchKernelGGL(k_scatter, tgrid, dim3(512), hist_lds, s, j->d_digits, lv_local(0), lv_tot(0), fill, j->d_entries, n,
-                       pl.W, pl.NB, pl.tile, shared);
-    level_ref ent{lv_local(0), lv_tot(0)};
     levels_dev L{};
     L.nlevels = nlevels;
     for (int r = 0; r < nlevels; r++) {
@@ -790,16 +937,15 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         L.parts[r] = j->d_partials + part_off[r];
     }
     // thread -> bucket maps of levels 0 and 1 (level 1 only exists when nlevels > 1)
-    uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
     hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
                        map0, map1, (uint32_t)NE, pl.ls0, pl.ls1);
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
     if (nseg > 1)
         hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
-                           ent, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
+                           ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
     else
         hipLaunchKernelGGL((k_accumulate<false>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
-                           ent, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
+                           ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
     for (int r = 1; r < nlevels; r++)
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r],
