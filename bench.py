@@ -26,8 +26,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Measured on MI355X by tools/ubench (profiles/r01_ubench.json): sustained v_mad_u64_u32, all CUs.
-VMAD_PEAK_GMACS = 26450.0
+# Measured on MI355X by tools/ubench (profiles/r01_ubench.json): sustained v_mad_u64_u32 issue, all CUs,
+# eight independent chains per lane with distinct multiplicands (the guide has no integer-multiply figure).
+VMAD_PEAK_GMACS = 28744.0
+# HBM-side bytes of one k_accumulate launch at 2^20 points, from rocprofv3 PMC passes (FETCH_SIZE doubled per the
+# guide's gfx950 correction, WRITE_SIZE as read): profiles/r01_pmc_*.csv.  bench.py cannot collect PMC itself.
+ACC_TRAFFIC_BYTES_2_20 = 3.04e9          # 2 x 1.44 GB fetched + 0.16 GB written (gathered table lines: every point is read once per window)
 # field mul = 72 MAC, mixed add = 7M = 504 MAC, canonical c = 16 -> 16 windows.
 MAC_PER_POINT_ACCUMULATE = 16 * 504          # bucket accumulation only (the dominant kernel)
 MAC_PER_POINT_MSM = 8640                     # W(2^20, 16), whole MSM
@@ -155,7 +159,9 @@ def main():
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
     ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "16")))
     ap.add_argument("--proofs-per-thread", type=int, default=4)
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "2")),
+    ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
+    ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "4")),
                     help="MSM jobs submitted before the oldest is waited for (each on its own stream)")
     args = ap.parse_args()
 
@@ -216,6 +222,10 @@ def main():
         return out
 
     run(args.warmup)
+    alone_us = []
+    for _ in range(3):                         # the dominant kernel with nothing else on the GPU (not in the timed region)
+        finish(ctx.msm_submit(pts, d_sc.ptr, n))
+        alone_us.append(ctx.msm_last_kernel_us()[0])
     acc_us = []
     barrier()
     t0 = time.perf_counter()
@@ -245,6 +255,58 @@ def main():
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
                               "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}
 
+    # ---- BASELINE configs[3]: ONE 2^20-multiplier proof, generator range sharded over the ranks, partial sums
+    #      all-gathered over RCCL (N = 1: unsharded, the scaling baseline)
+    big = None
+    if not args.no_big_proof:
+        try:
+            from tools import sharded_proof as sp
+            from bulletproofs_gadgets_amd import r1cs as g
+            nbits = int(os.environ.get("BPG_BENCH_BIG_BITS", "38836"))
+            cap = 1 << (27 * nbits + 3).bit_length()
+            shard = (rank, world, g.make_all_gather(dist, "cuda")) if world > 1 else None
+            t0 = time.perf_counter()
+            gens = g.BulletproofGens(ctx, cap, 1, shard=shard)
+            gens_s = time.perf_counter() - t0
+            stmt = sp.statement(nbits)
+            best = None
+            for _ in range(2):
+                barrier()
+                proof, cap_s, prove_s, verify_s, tm = sp.prove_and_verify(g, gens, nbits, stmt)
+                if best is None or prove_s < best[1]:
+                    best = (cap_s, prove_s, verify_s, tm)
+            gens.free()
+            import hashlib
+            big = {"workload": "Edwards scalar_mul gadget, %d committed bits -> %d multipliers (BASELINE configs[3]); every MSM of "
+                               "prove/verify split by generator range over the ranks, 128-byte partial sums all-gathered" % (nbits, 27 * nbits + 4),
+                   "ranks": world, "gens_setup_s": round(gens_s, 3), "capture_commit_s": round(best[0], 3), "prove_s": round(best[1], 4),
+                   "verify_s": round(best[2], 4), "prover_timing_ms": {k: round(v, 1) for k, v in best[3].items()},
+                   "proof_sha256": hashlib.sha256(proof.to_bytes()).hexdigest()}
+        except Exception as e:  # noqa: BLE001  (the headline line must survive a failure here)
+            big = {"error": repr(e)}
+    # ---- BASELINE configs[4]: 4096 Ristretto-gadget proofs per GPU, verified by one combined MSM (no collective)
+    batch = None
+    if not args.no_batch:
+        try:
+            from tools import batch_verify as bv
+            from bulletproofs_gadgets_amd import r1cs as g
+            gens = g.BulletproofGens(ctx, 256, 1)
+            barrier()
+            batch = bv.run(ctx, gens, int(os.environ.get("BPG_BENCH_BATCH", "4096")), args.proof_threads, rank)
+            barrier()
+            gens.free()
+            if world > 1:
+                tt = torch.tensor([batch["prove_s"], batch["verify_batch_s"], batch["verify_one_by_one_s"]], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ps, vb, vs_ = (float(x) for x in tt.tolist())
+                k = batch["proofs"]
+                batch.update({"proofs": k * world, "prove_s": round(ps, 3), "verify_batch_s": round(vb, 3), "verify_one_by_one_s": round(vs_, 3),
+                              "proofs_per_s_prove": round(k * world / ps, 1), "proofs_per_s_verify_batch": round(k * world / vb, 1),
+                              "proofs_per_s_verify_single": round(k * world / vs_, 1)})
+            batch["workload"] = "P1 + P2 = P3 with SonnyRistrettoPointGadget (134 multipliers); proofs sharded across GPUs, one combined MSM per GPU"
+        except Exception as e:  # noqa: BLE001
+            batch = {"error": repr(e)}
+
     if rank == 0:
         plan = ctx.msm_plan(n)
         acc = sum(acc_us) / len(acc_us) if acc_us else float("nan")
@@ -267,10 +329,12 @@ def main():
                        "in_flight": args.in_flight, "table_build_s": round(table_s, 4), "result": result.hex()},
             "roofline": {"bound": "valu_int32 (v_mad_u64_u32 issue)", "kernel": "k_accumulate",
                          "achieved": achieved, "peak": VMAD_PEAK_GMACS, "unit": "GMAC/s", "frac": achieved / VMAD_PEAK_GMACS,
-                         "kernel_avg_us": acc, "algorithmic_mac_per_point": MAC_PER_POINT_ACCUMULATE,
+                         "kernel_avg_us": acc, "kernel_alone_us": min(alone_us), "frac_alone": MAC_PER_POINT_ACCUMULATE * n / (min(alone_us) * 1e-6) / 1e9 / VMAD_PEAK_GMACS,
+                         "note": "kernel_avg_us is measured in the timed region, where %d MSMs are in flight and share the GPU; kernel_alone_us is the same kernel with the GPU to itself" % args.in_flight,
+                         "algorithmic_mac_per_point": MAC_PER_POINT_ACCUMULATE,
                          "executed_mac_per_point": plan["windows"] * 504,
                          "hbm_algorithmic_GBps": BYTES_PER_POINT * n / (acc * 1e-6) / 1e9, "hbm_peak_GBps": 8000.0,
-                         "traffic": None},
+                         "traffic": ACC_TRAFFIC_BYTES_2_20 if args.logn == 20 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = min(n, 1 << 18)
@@ -287,6 +351,10 @@ def main():
                                                     "statement, 1 proof, %.1f s" % cpu_s,
                                           "proof_bytes_equal_gpu": cpu_proof == first_proof.to_bytes()}
             line["secondary"] = proofs
+        if big is not None:
+            line["proof_2_20"] = big
+        if batch is not None:
+            line["batch_4096"] = batch
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -255,6 +255,10 @@ int bpg_init(int device_id, bpg_ctx **out) {
     }
     if (device_id < 0 || device_id >= count) return BPG_EINVAL;
     BPG_CHECK_HIP(hipSetDevice(device_id));
+    // BPG_SYNC=block: host threads sleep in stream / event waits instead of spinning (many prover
+    // threads per GPU share the host cores with circuit capture and the transcript's Keccak chain)
+    if (const char *s = getenv("BPG_SYNC"))
+        if (!strcmp(s, "block")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     bpg_ctx *ctx = new bpg_ctx();
     ctx->device = device_id;
     ctx->id = g_next_ctx_id.fetch_add(1);
