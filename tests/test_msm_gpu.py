@@ -126,3 +126,56 @@ def test_msm_linearity_at_size(gpu_ctx):
     two = gpu_ctx.points_from_compressed(ra + rb)
     one = (1).to_bytes(32, "little")
     assert gpu_ctx.msm(two, one + one) == rab
+
+
+@pytest.mark.parametrize("logn", [20, 22])
+def test_msm_full_size_properties(gpu_ctx, logn):
+    """BASELINE config 2 at its full sizes (2^20, 2^22), where the oracle would take minutes:
+    size-independent properties instead.  (a) additivity over a point-range split, which is also the
+    multi-GPU decomposition: MSM(all) == combine(partial(first 3/8), partial(rest)); (b) MSM(s) + MSM(l - s)
+    == identity; (c) a sparse scalar vector (one non-zero entry per 2^14) equals the small MSM over exactly
+    those points, which the oracle-checked sizes cover."""
+    import numpy as np
+    from bulletproofs_gadgets_amd import _native
+    n = 1 << logn
+    pts = gpu_ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"full%d" % logn))
+    rng = np.random.default_rng(logn)
+    raw = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x0f                                   # < 2^252 < l: canonical
+    sc = raw.tobytes()
+    buf = gpu_ctx.alloc(len(sc)).upload(sc)
+    full = gpu_ctx.msm_submit(pts, buf.ptr, n).wait()
+    assert full != bytes(32)
+    # (a) range split 3/8 : 5/8 through the segment API and the partial-sum combine
+    cut = 3 * n // 8
+    p1 = gpu_ctx.msm_submit(pts, buf.ptr, cut, 1, segments=[(0, cut)]).wait_partial()
+    p2 = gpu_ctx.msm_submit(pts, buf.ptr + 32 * cut, n - cut, 1, segments=[(cut, n - cut)]).wait_partial()
+    assert _native.combine_partials(p1 + p2) == full
+    # (b) negated scalars cancel: l - s, computed with numpy on 4 x u64 limbs
+    limbs = raw.view("<u8").reshape(n, 4)
+    neg = np.zeros((n, 4), dtype=np.uint64)
+    borrow = np.zeros(n, dtype=bool)
+    for k in range(4):
+        lk = np.uint64((L >> (64 * k)) & (2**64 - 1))
+        with np.errstate(over="ignore"):
+            neg[:, k] = lk - limbs[:, k] - borrow.astype(np.uint64)
+        borrow = (limbs[:, k] > lk) | ((limbs[:, k] == lk) & borrow)
+    assert not borrow.any()
+    negb = neg.astype("<u8").tobytes()
+    nbuf = gpu_ctx.alloc(len(negb)).upload(negb)
+    pn = gpu_ctx.msm_submit(pts, nbuf.ptr, n).wait_partial()
+    pf = gpu_ctx.msm_submit(pts, buf.ptr, n).wait_partial()
+    assert _native.combine_partials(pf + pn) == bytes(32)
+    # (c) sparse vector == small dense MSM over the selected points
+    step = 1 << 14
+    idx = list(range(5, n, step))
+    sparse = bytearray(32 * n)
+    small = b""
+    for j, i in enumerate(idx):
+        s = synth.scalars(1, tag=b"sp%d" % j)
+        sparse[32 * i:32 * i + 32] = s
+        small += s
+    sbuf = gpu_ctx.alloc(len(sparse)).upload(bytes(sparse))
+    got = gpu_ctx.msm_submit(pts, sbuf.ptr, n).wait()
+    sel = gpu_ctx.points_from_compressed(b"".join(pts.compress(i, 1) for i in idx))
+    assert got == gpu_ctx.msm(sel, small)
