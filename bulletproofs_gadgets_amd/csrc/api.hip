@@ -262,6 +262,11 @@ int bpg_init(int device_id, bpg_ctx **out) {
     bpg_ctx *ctx = new bpg_ctx();
     ctx->device = device_id;
     ctx->id = g_next_ctx_id.fetch_add(1);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            ctx->resident_lanes = cus * 4 * 4 * 64;
+    }
     if (const char *s = getenv("BPG_MSM_C")) ctx->tune.c = atoi(s);
     if (const char *s = getenv("BPG_MSM_TILE")) ctx->tune.tile = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);

@@ -43,8 +43,8 @@ struct msm_plan {
     int W;            // digit windows = ceil(252 / c)
     int Wb;           // bucket sets per target: W (variable-base) or 1 (fixed-base: all windows share one)
     int NB;           // buckets per window = 2^(c-1)
-    int P;            // entries per accumulate thread = 2^ls0
-    int ls0, ls1;     // log2 of the segment sizes: S0 entries / thread, S1 partials / merge thread
+    int P;            // entries per accumulate thread (= ls0)
+    int ls0, ls1;     // ls0: S0, entries per accumulate thread (any integer); ls1: log2 of S1, partials per merge thread
     int R;            // reduction passes after the accumulate pass
     int tile;         // scalars per histogram tile
     int ntiles;
@@ -59,7 +59,7 @@ struct msm_plan {
 struct msm_tuning {
     int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
 };
-msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c = 0);
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c = 0, float density = 1.f, int resident_lanes = 262144);
 // fixed-base (precomputed 2^(c w) multiples) geometry for a table of `points` generators
 int fixed_base_window(size_t points);
 int fixed_base_windows(int c);
@@ -124,6 +124,7 @@ struct bpg_ctx {
     int device = 0;
     uint64_t id = 0;                  // process-unique; keys the per-thread lane cache
     bpg::msm_tuning tune;
+    int resident_lanes = 262144;      // CUs x 4 SIMDs x 4 waves x 64 lanes: threads of k_accumulate resident at once
     std::mutex mu;                    // guards lanes
     std::vector<bpg_lane *> lanes;
 };
@@ -144,6 +145,7 @@ struct msm_seg {
 struct msm_fixed_base {
     int c = 0;
     size_t wstride = 0;
+    float density = 1.f;    // hint: expected fraction of non-zero scalars (sizes the accumulate segments)
 };
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *scalars, size_t n, int T, bool scalars_on_host,
                bpg_msm_job **out_job, msm_fixed_base fb = msm_fixed_base(), size_t sc_stride = 0);

@@ -106,6 +106,19 @@ BPG_HD void ge_add(ge &r, const ge &p, const ge &q) {
     fe_mul(r.Z, f, g);
 }
 
+#if defined(__HIPCC__)
+// xor-butterfly exchange of an extended point inside groups of `width` lanes
+__device__ __forceinline__ void ge_shfl_xor(ge &r, const ge &p, int mask, int width) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.X.v[i] = __shfl_xor(p.X.v[i], mask, width);
+        r.Y.v[i] = __shfl_xor(p.Y.v[i], mask, width);
+        r.Z.v[i] = __shfl_xor(p.Z.v[i], mask, width);
+        r.T.v[i] = __shfl_xor(p.T.v[i], mask, width);
+    }
+}
+#endif
+
 BPG_HD void ge_neg(ge &r, const ge &p) {
     fe_neg(r.X, p.X);
     r.Y = p.Y;

@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ b
 //   level -1: cnt            level 0: ceil(cnt/S0)           level r: ceil(level r-1 / S1)
 __device__ __forceinline__ uint32_t seg_count(uint32_t cnt, int level, int ls0, int ls1) {
     if (level < 0) return cnt;
-    uint32_t x = (cnt + (1u << ls0) - 1) >> ls0;
+    uint32_t x = (cnt + (uint32_t)ls0 - 1) / (uint32_t)ls0;      // ls0: S0, the segment size (any integer >= 1)
     for (int i = 0; i < level; i++) x = (x + (1u << ls1) - 1) >> ls1;
     return x;
 }
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
     const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
     uint32_t cnt = counts[g];
     uint32_t off = ent_off[g];
-    uint32_t lo = rank << ls0, hi = lo + (1u << ls0);
+    uint32_t lo = rank * (uint32_t)ls0, hi = lo + (uint32_t)ls0;
     hi = hi < cnt ? hi : cnt;
     ge acc;
     ge_identity(acc);
@@ -622,6 +622,48 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t *__restrict__ cou
     store_ge(parts_out + t, acc);
 }
 
+// The same merge for small problems (a proof-sized MSM has ~16 k buckets: one thread per merge
+// leaves most of the GPU idle while each walks up to 15 dependent additions).  G lanes per merge:
+// every lane adds 16/G partials, log2(G) butterfly steps add the lanes up (S1 must be 16).
+// A little more total work, a fraction of the latency; chosen by the host when buckets are few.
+template <int G>
+__global__ void __launch_bounds__(256) k_reduce_wide(const uint32_t *__restrict__ counts, level_ref prev, level_ref cur,
+                                                     const uint32_t *__restrict__ map, const ge_rec *__restrict__ parts_in,
+                                                     ge_rec *__restrict__ parts_out, uint32_t nblk, uint32_t ne, int level,
+                                                     int ls0) {
+    constexpr int PER = 16 / G;
+    const uint32_t lane_id = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = lane_id / G, sub = lane_id % G;
+    if (t >= cur.base[nblk]) return;               // uniform over the G lanes of a merge
+    uint32_t rank, g;
+    if (map) {
+        g = map[t];
+        rank = t - (cur.local[g] + cur.base[g >> 10]);
+    } else {
+        g = find_bucket(cur, t, nblk, ne, rank);
+    }
+    const uint32_t kprev = seg_count(counts[g], level - 1, ls0, 4);
+    const uint32_t in0 = prev.local[g] + prev.base[g >> 10];
+    const uint32_t first = (rank << 4) + sub * PER;
+    ge acc;
+    if (first < kprev) load_ge(acc, parts_in + in0 + first);
+    else ge_identity(acc);
+    for (int k = 1; k < PER; k++) {
+        if (first + k < kprev) {
+            ge b;
+            load_ge(b, parts_in + in0 + first + k);
+            ge_add(acc, acc, b);
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        ge other;
+        ge_shfl_xor(other, acc, o, G);
+        ge_add(acc, acc, other);
+    }
+    if (sub == 0) store_ge(parts_out + t, acc);
+}
+
 struct levels_dev {
     level_ref lv[MAX_LEVELS];
     const ge_rec *parts[MAX_LEVELS];
@@ -635,7 +677,7 @@ __device__ __forceinline__ void bucket_sum(ge &acc, const levels_dev &L, const u
         ge_identity(acc);
         return;
     }
-    uint32_t k = (cnt + (1u << ls0) - 1) >> ls0;
+    uint32_t k = (cnt + (uint32_t)ls0 - 1) / (uint32_t)ls0;
     int r = 0;
     while (k > 1 && r + 1 < L.nlevels) {
         k = (k + (1u << ls1) - 1) >> ls1;
@@ -720,7 +762,7 @@ int fixed_base_window(size_t points) {
 }
 int fixed_base_windows(int c) { return windows_for(c); }
 
-msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c) {
+msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float density, int resident_lanes) {
     msm_plan pl{};
     int c = auto_window(n);
     if (tune.c >= 2 && tune.c <= 14) c = tune.c;
@@ -729,13 +771,18 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c) {
     pl.W = windows_for(c);
     pl.Wb = fixed_c ? 1 : pl.W;
     pl.NB = 1 << (c - 1);
-    pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 8) ? tune.ls0 : 4;
+    // S0 = entries per accumulate thread (any integer).  Measured: shrinking S0 so that a proof-sized MSM's threads
+    // just fill the machine does not pay -- the pass is bound by total additions once two waves share a SIMD, and
+    // more partials make the merge passes longer.
+    (void)density;
+    (void)resident_lanes;
+    pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 256) ? tune.ls0 : 16;
     pl.ls1 = (tune.ls1 >= 1 && tune.ls1 <= 8) ? tune.ls1 : 4;
-    pl.P = 1 << pl.ls0;
+    pl.P = pl.ls0;
     // passes: S0 * S1^R >= the most entries one bucket can hold
     const size_t worst = fixed_c ? n * (size_t)pl.W : n;
     int R = 0;
-    while (((size_t)1 << (pl.ls0 + pl.ls1 * R)) < worst) R++;
+    while (((size_t)pl.ls0 << (pl.ls1 * R)) < worst) R++;
     pl.R = R;
     int tile = 4096;
     while (tile < 32768 && (size_t)tile * 64 < n) tile *= 2;
@@ -850,7 +897,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if (!lane) return BPG_EDEVICE;
     bpg_msm_job *j = acquire_job(lane);
     if (!j) return BPG_EDEVICE;
-    msm_plan pl = make_plan(n, T, ctx->tune, fb.c);
+    msm_plan pl = make_plan(n, T, ctx->tune, fb.c, fb.density, ctx->resident_lanes);
     j->plan = pl;
     const size_t NE = (size_t)T * pl.Wb * pl.NB;          // buckets
     const size_t M = (size_t)T * pl.W * n;                // upper bound on entries
@@ -882,8 +929,12 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     }
     // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
     size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS], part_total = 0;
-    cap_lv[0] = (M >> pl.ls0) + NE + 1;
-    for (int r = 1; r < nlevels; r++) cap_lv[r] = cap_lv[r - 1] / 2 + 1;
+    cap_lv[0] = M / (size_t)pl.ls0 + NE + 1;
+    for (int r = 1; r < nlevels; r++) {
+        // a bucket with cnt entries has <= cnt / (S0 S1^r) + 1 threads at level r, and at most half of level r-1
+        const size_t by_count = ((M / (size_t)pl.ls0) >> (r * pl.ls1)) + NE + 1;
+        cap_lv[r] = cap_lv[r - 1] / 2 + 1 < by_count ? cap_lv[r - 1] / 2 + 1 : by_count;
+    }
     for (int r = 0; r < nlevels; r++) {
         part_off[r] = part_total;
         part_total += cap_lv[r];
@@ -947,10 +998,18 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         hipLaunchKernelGGL((k_accumulate<false>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
                            ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
-    for (int r = 1; r < nlevels; r++)
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r],
-                           r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr, j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
-                           pl.ls0, pl.ls1);
+    const bool wide = pl.ls1 == 4 && NE <= 32768;          // latency-bound regime: 4 lanes per merge
+    for (int r = 1; r < nlevels; r++) {
+        const uint32_t *mp = r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr;
+        if (wide)
+            hipLaunchKernelGGL((k_reduce_wide<4>), dim3((unsigned)((cap_lv[r] * 4 + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1],
+                               L.lv[r], mp, j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk,
+                               (uint32_t)NE, r, pl.ls0);
+        else
+            hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r], mp,
+                               j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
+                               pl.ls0, pl.ls1);
+    }
     ge_rec *a_out = pl.nchunks == 1 ? j->d_out : j->d_chunk;
     hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,
                        pl.chunk, logchunk, pl.Wb, pl.ls0, pl.ls1);

@@ -293,22 +293,29 @@ __global__ void __launch_bounds__(256) k_axpy(uint32_t n, sc rho, const sc *__re
 }
 
 // K3: fixed-base Pedersen commitments v B + r B~ with radix-16 comb tables, compressed on the device.
-// comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels)
-__global__ void __launch_bounds__(64) k_pedersen(const aniels_rec *__restrict__ comb, const sc *__restrict__ scalars /* [m][2] */,
-                                                 uint32_t m, uint8_t *__restrict__ out32) {
-    uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= m) return;
+// comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels).  16 lanes per commitment: lane l
+// adds the windows w = l mod 16 of both scalars (8 mixed additions), four butterfly steps sum the
+// lanes, lane 0 compresses.  (One lane per commitment walked 128 dependent additions: 0.64 ms for
+// any batch size.)
+__global__ void __launch_bounds__(256) k_pedersen(const aniels_rec *__restrict__ comb, const sc *__restrict__ scalars /* [m][2] */,
+                                                  uint32_t m, uint8_t *__restrict__ out32) {
+    const uint32_t lane_id = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = lane_id >> 4, sub = lane_id & 15u;
+    if (i >= m) return;                            // uniform over the 16 lanes of a commitment
     ge acc;
     ge_identity(acc);
     for (int base = 0; base < 2; base++) {
         sc s = ld_sc(scalars + 2 * (size_t)i + base);
-        uint32_t carry = 0;
-        for (int w = 0; w < 64; w++) {
-            uint32_t raw = ((s.v[w >> 3] >> ((w & 7) * 4)) & 15u) + carry;
-            carry = raw > 8 ? 1u : 0u;
-            int d = (int)raw - (int)(carry << 4);
+        // signed radix-16 digits without a serial carry: s + 0x88..8 (s < 2^253: no overflow), digit = nibble - 8
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s.v[k] = addc32(s.v[k], 0x88888888u, c, c);
+#pragma unroll
+        for (int jw = 0; jw < 4; jw++) {
+            const int w = (int)sub + 16 * jw;
+            const int d = (int)((s.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
             if (d != 0) {
-                int k = d < 0 ? -d : d;
+                const int k = d < 0 ? -d : d;
                 const uint32_t *rec = comb[(size_t)(base * 64 + w) * 8 + (k - 1)].w;
                 ge_aniels q;
 #pragma unroll
@@ -320,8 +327,14 @@ __global__ void __launch_bounds__(64) k_pedersen(const aniels_rec *__restrict__ 
                 ge_madd(acc, acc, q, d < 0);
             }
         }
-        // scalars are < 2^253, so the final carry is always 0
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        ge other;
+        ge_shfl_xor(other, acc, o, 16);
+        ge_add(acc, acc, other);
+    }
+    if (sub != 0) return;
     uint32_t enc[8];
     ristretto_encode_w(enc, acc);
     uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * (size_t)i);
@@ -671,7 +684,7 @@ static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     BPG_CHECK_HIP(hipMalloc((void **)&d_s, m * 64));
     BPG_CHECK_HIP(hipMalloc((void **)&d_o, m * 32));
     BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
+    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
@@ -721,11 +734,12 @@ static int finish_partials(Gens *g, const uint8_t *mine, int T, uint8_t *out32) 
 
 // One fixed-base MSM with T targets over this rank's part of the generator table.  Rows of
 // `stride` scalars each; segment k reads its scalars at segs[k].sc_off.
-static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, size_t stride, int T, uint8_t *out32) {
+static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, size_t stride, int T, uint8_t *out32,
+                    float density = 1.f) {
     size_t n = 0;
     for (int k = 0; k < nseg; k++) n += segs[k].len;
     bpg_msm_job *job = nullptr;
-    int rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints()}, stride);
+    int rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints(), density}, stride);
     if (rc) return rc;
     if (g->world == 1) return msm_wait(job, out32, false);
     std::vector<uint8_t> mine((size_t)T * 128);
@@ -958,7 +972,7 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
         BPG_CHECK_HIP(hipStreamSynchronize(s));
         msm_seg segs[3] = {gen_seg(gens_, 0, 0, np, 0), gen_seg(gens_, 1, 0, np, np), pedersen_seg(gens_, 0, 1, 2 * np)};
         uint8_t out[64];
-        if ((rc = gens_msm(gens_, segs, 3, d_rowLR, NR, 2, out))) return rc;
+        if ((rc = gens_msm(gens_, segs, 3, d_rowLR, NR, 2, out, 0.5f))) return rc;     // half of every row is zero
         memcpy(&P.L_vec[32 * k], out, 32);
         memcpy(&P.R_vec[32 * k], out + 32, 32);
         tr_.append_point("L", out);
