@@ -59,13 +59,99 @@ struct Term {
     Scalar coeff;
 };
 
+// Terms of a linear combination: the gadgets build tens of thousands of short-lived LCs with one to
+// five terms each, so the first INLINE terms live inside the object (no heap traffic during capture).
+class TermVec {
+  public:
+    static constexpr uint32_t INLINE = 6;
+    TermVec() {}
+    TermVec(const TermVec &o) { assign(o); }
+    TermVec(TermVec &&o) noexcept { steal(o); }
+    TermVec &operator=(const TermVec &o) {
+        if (this != &o) {
+            n_ = 0;
+            assign(o);
+        }
+        return *this;
+    }
+    TermVec &operator=(TermVec &&o) noexcept {
+        if (this != &o) {
+            release();
+            steal(o);
+        }
+        return *this;
+    }
+    ~TermVec() { release(); }
+    size_t size() const { return n_; }
+    const Term *begin() const { return data(); }
+    const Term *end() const { return data() + n_; }
+    const Term &operator[](size_t i) const { return data()[i]; }
+    void reserve(size_t want) {
+        if (want > cap_) grow(want);
+    }
+    void push_back(const Term &t) {
+        if (n_ == cap_) grow((size_t)cap_ * 2);
+        data()[n_++] = t;
+    }
+    void append(const TermVec &o) {
+        const uint32_t m = o.n_;                 // (o may be *this)
+        reserve((size_t)n_ + m);
+        const Term *src = o.data();
+        Term *dst = data();
+        for (uint32_t i = 0; i < m; i++) dst[n_ + i] = src[i];
+        n_ += m;
+    }
+
+  private:
+    Term *data() { return heap_ ? heap_ : inl_; }
+    const Term *data() const { return heap_ ? heap_ : inl_; }
+    void grow(size_t want) {
+        Term *nw = new Term[want];
+        const Term *old = data();
+        for (uint32_t i = 0; i < n_; i++) nw[i] = old[i];
+        delete[] heap_;
+        heap_ = nw;
+        cap_ = (uint32_t)want;
+    }
+    void assign(const TermVec &o) {
+        reserve(o.n_);
+        const Term *src = o.data();
+        Term *dst = data();
+        for (uint32_t i = 0; i < o.n_; i++) dst[i] = src[i];
+        n_ = o.n_;
+    }
+    void steal(TermVec &o) {
+        if (o.heap_) {
+            heap_ = o.heap_;
+            cap_ = o.cap_;
+            o.heap_ = nullptr;
+            o.cap_ = INLINE;
+        } else {
+            heap_ = nullptr;
+            cap_ = INLINE;
+            for (uint32_t i = 0; i < o.n_; i++) inl_[i] = o.inl_[i];
+        }
+        n_ = o.n_;
+        o.n_ = 0;
+    }
+    void release() {
+        delete[] heap_;
+        heap_ = nullptr;
+        cap_ = INLINE;
+        n_ = 0;
+    }
+    Term inl_[INLINE];
+    Term *heap_ = nullptr;
+    uint32_t n_ = 0, cap_ = INLINE;
+};
+
 struct LinearCombination {
-    std::vector<Term> terms;
+    TermVec terms;
     LinearCombination() {}
     LinearCombination(const Variable &v) { terms.push_back({v, Scalar(1)}); }
     LinearCombination(const Scalar &s) { terms.push_back({Variable::One(), s}); }
     LinearCombination &operator+=(const LinearCombination &o) {
-        terms.insert(terms.end(), o.terms.begin(), o.terms.end());
+        terms.append(o.terms);
         return *this;
     }
     LinearCombination &operator-=(const LinearCombination &o) {
@@ -95,6 +181,7 @@ struct ConstraintStore {
     std::vector<sc> coeffs;
     std::unordered_map<uint64_t, std::vector<uint32_t>> coeff_lookup;   // hash -> ids
     uint32_t num_constraints = 0;
+    uint32_t id_one = 0xffffffffu, id_minus_one = 0xffffffffu;       // almost every coefficient is +1 or -1
     uint32_t intern(const sc &c);
     void push(const LinearCombination &lc);
 };

@@ -376,6 +376,22 @@ __global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict_
 // =================================================================== host: store / sonny / proof bytes
 
 uint32_t ConstraintStore::intern(const sc &c) {
+    static const sc one = sc_one();
+    static const sc minus_one = (-Scalar(1)).v;
+    if (sc_eq(c, one)) {
+        if (id_one == 0xffffffffu) {
+            coeffs.push_back(c);
+            id_one = (uint32_t)coeffs.size() - 1;
+        }
+        return id_one;
+    }
+    if (sc_eq(c, minus_one)) {
+        if (id_minus_one == 0xffffffffu) {
+            coeffs.push_back(c);
+            id_minus_one = (uint32_t)coeffs.size() - 1;
+        }
+        return id_minus_one;
+    }
     uint64_t h = ((uint64_t)c.v[1] << 32 | c.v[0]) ^ ((uint64_t)c.v[7] << 32 | c.v[4]) * 0x9e3779b97f4a7c15ULL;
     auto &ids = coeff_lookup[h];
     for (uint32_t id : ids)
@@ -774,15 +790,23 @@ void Prover::commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, u
 }
 
 Scalar Prover::eval(const LinearCombination &lc) const {
+    static const sc one = sc_one();
+    static const sc minus_one = (-Scalar(1)).v;
     Scalar acc(0);
     for (const auto &t : lc.terms) {
+        const sc *val;
         switch (t.var.kind) {
-            case VAR_LEFT: acc += t.coeff * Scalar(a_L_[t.var.index]); break;
-            case VAR_RIGHT: acc += t.coeff * Scalar(a_R_[t.var.index]); break;
-            case VAR_OUTPUT: acc += t.coeff * Scalar(a_O_[t.var.index]); break;
-            case VAR_COMMITTED: acc += t.coeff * Scalar(v_[t.var.index]); break;
-            default: acc += t.coeff; break;
+            case VAR_LEFT: val = &a_L_[t.var.index]; break;
+            case VAR_RIGHT: val = &a_R_[t.var.index]; break;
+            case VAR_OUTPUT: val = &a_O_[t.var.index]; break;
+            case VAR_COMMITTED: val = &v_[t.var.index]; break;
+            default: val = &one; break;
         }
+        // almost every coefficient in the gadget circuits is +1 or -1: no multiplication then
+        if (sc_eq(t.coeff.v, one)) acc += Scalar(*val);
+        else if (sc_eq(t.coeff.v, minus_one)) acc -= Scalar(*val);
+        else if (val == &one) acc += t.coeff;
+        else acc += t.coeff * Scalar(*val);
     }
     return acc;
 }
