@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--logn", type=int, default=int(os.environ.get("BPG_BENCH_LOGN", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
-    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "16")))
+    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "24")))
     ap.add_argument("--proofs-per-thread", type=int, default=4)
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
@@ -172,8 +172,16 @@ def main():
     if world > 1:
         import torch                           # torch first: its HIP runtime is the one both sides then share
         import torch.distributed as dist
+        # BPG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with several ranks sharing one GPU (CPU tensors in the
+        # collectives); the real run is one rank per GPU over RCCL ("nccl")
+        backend = os.environ.get("BPG_BENCH_BACKEND", "nccl")
+        local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        cdev = "cuda" if backend == "nccl" else "cpu"
 
     import bulletproofs_gadgets_amd as bpg
     from bulletproofs_gadgets_amd import _native, synth
@@ -190,8 +198,8 @@ def main():
     d_sc = ctx.alloc(len(sc)).upload(sc)
 
     if world > 1:
-        gather_in = torch.empty(128, dtype=torch.uint8, device="cuda")
-        gather_out = torch.empty(128 * world, dtype=torch.uint8, device="cuda")
+        gather_in = torch.empty(128, dtype=torch.uint8, device=cdev)
+        gather_out = torch.empty(128 * world, dtype=torch.uint8, device=cdev)
 
     def finish(job):
         part = job.wait_partial()
@@ -233,7 +241,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -244,7 +252,7 @@ def main():
         cnt, s_prove, s_pv, lat, first_proof = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread)
         barrier()
         if world > 1:
-            tt = torch.tensor([s_prove, s_pv], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([s_prove, s_pv], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             s_prove, s_pv = (float(x) for x in tt.tolist())
         proofs = {"metric": "R1CS proofs/s at 2^16 multipliers", "unit": "proofs/s",
@@ -264,7 +272,7 @@ def main():
             from bulletproofs_gadgets_amd import r1cs as g
             nbits = int(os.environ.get("BPG_BENCH_BIG_BITS", "38836"))
             cap = 1 << (27 * nbits + 3).bit_length()
-            shard = (rank, world, g.make_all_gather(dist, "cuda")) if world > 1 else None
+            shard = (rank, world, g.make_all_gather(dist, cdev if cdev == "cuda" else None)) if world > 1 else None
             t0 = time.perf_counter()
             gens = g.BulletproofGens(ctx, cap, 1, shard=shard)
             gens_s = time.perf_counter() - t0
@@ -296,7 +304,7 @@ def main():
             barrier()
             gens.free()
             if world > 1:
-                tt = torch.tensor([batch["prove_s"], batch["verify_batch_s"], batch["verify_one_by_one_s"]], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([batch["prove_s"], batch["verify_batch_s"], batch["verify_one_by_one_s"]], dtype=torch.float64, device=cdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ps, vb, vs_ = (float(x) for x in tt.tolist())
                 k = batch["proofs"]
