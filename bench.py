@@ -304,12 +304,15 @@ def main():
             barrier()
             gens.free()
             if world > 1:
-                tt = torch.tensor([batch["prove_s"], batch["verify_batch_s"], batch["verify_one_by_one_s"]], dtype=torch.float64, device=cdev)
+                tt = torch.tensor([batch["prove_s"], batch["verify_batch_s"], batch["verify_one_by_one_s"], batch["verify_batch_threads_s"]],
+                                  dtype=torch.float64, device=cdev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                ps, vb, vs_ = (float(x) for x in tt.tolist())
+                ps, vb, vs_, vt = (float(x) for x in tt.tolist())
                 k = batch["proofs"]
                 batch.update({"proofs": k * world, "prove_s": round(ps, 3), "verify_batch_s": round(vb, 3), "verify_one_by_one_s": round(vs_, 3),
+                              "verify_batch_threads_s": round(vt, 3),
                               "proofs_per_s_prove": round(k * world / ps, 1), "proofs_per_s_verify_batch": round(k * world / vb, 1),
+                              "proofs_per_s_verify_batch_threads": round(k * world / vt, 1),
                               "proofs_per_s_verify_single": round(k * world / vs_, 1)})
             batch["workload"] = "P1 + P2 = P3 with SonnyRistrettoPointGadget (134 multipliers); proofs sharded across GPUs, one combined MSM per GPU"
         except Exception as e:  # noqa: BLE001

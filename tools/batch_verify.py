@@ -69,9 +69,26 @@ def run(ctx, gens, k, threads, rank=0):
     t0 = time.perf_counter()
     vs = verifiers(0, k)
     synth_s = time.perf_counter() - t0
+    rnd = hashlib.shake_256(b"bv-rng").digest(64 * k)
     t0 = time.perf_counter()
-    ok = g.verify_batch(vs, proofs, gens, hashlib.shake_256(b"bv-rng").digest(64 * k))
+    ok = g.verify_batch(vs, proofs, gens, rnd)
     batch_s = time.perf_counter() - t0
+    # the same batch as `threads` sub-batches, one host thread and one combined MSM each
+    vs = verifiers(0, k)
+    oks = [False] * threads
+
+    def verify_range(t, lo, hi):
+        try:
+            oks[t] = lo >= hi or g.verify_batch(vs[lo:hi], proofs[lo:hi], gens, rnd[64 * lo:64 * hi])
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=verify_range, args=(t, t * per, min(k, (t + 1) * per))) for t in range(threads)]
+    t0 = time.perf_counter()
+    [t.start() for t in th]
+    [t.join() for t in th]
+    batch_mt_s = time.perf_counter() - t0
+    assert not errs, errs
+    ok = bool(ok) and all(oks)
     ksingle = min(k, 256)
     vs = verifiers(0, ksingle)
     t0 = time.perf_counter()
@@ -91,6 +108,7 @@ def run(ctx, gens, k, threads, rank=0):
     return {"proofs": k, "multipliers": 134, "prove_threads": threads, "prove_s": round(prove_s, 3),
             "proofs_per_s_prove": round(k / prove_s, 1), "verifier_synthesis_s": round(synth_s, 3),
             "verify_batch_s": round(batch_s, 3), "proofs_per_s_verify_batch": round(k / batch_s, 1),
+            "verify_batch_threads_s": round(batch_mt_s, 3), "proofs_per_s_verify_batch_threads": round(k / batch_mt_s, 1),
             "verify_one_by_one_s": round(single_s, 3), "proofs_per_s_verify_single": round(k / single_s, 1),
             "batch_ok": bool(ok), "bad_batch_rejected": rejected}
 
