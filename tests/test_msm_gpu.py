@@ -179,3 +179,34 @@ def test_msm_full_size_properties(gpu_ctx, logn):
     got = gpu_ctx.msm_submit(pts, sbuf.ptr, n).wait()
     sel = gpu_ctx.points_from_compressed(b"".join(pts.compress(i, 1) for i in idx))
     assert got == gpu_ctx.msm(sel, small)
+
+
+@pytest.mark.parametrize("env", [{"BPG_MSM_LS0": "1"}, {"BPG_MSM_LS0": "5"}, {"BPG_MSM_LS0": "23", "BPG_MSM_LS1": "3"},
+                                 {"BPG_MSM_C": "9", "BPG_MSM_TILE": "512"}, {"BPG_MSM_C": "12", "BPG_MSM_LS0": "64"},
+                                 {"BPG_MSM_C": "6", "BPG_MSM_LS1": "2"}])
+def test_msm_planner_overrides(oracle, env):
+    """every geometry the planner can be pushed into (segment size S0 not a power of two, narrow and wide
+    merge passes, deep merge trees, small tiles, one and many buckets per bin) gives the oracle's bytes,
+    on uniform and on skewed scalars"""
+    import os
+    import bulletproofs_gadgets_amd as bpg
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        ctx = bpg.Context(0)              # the overrides are read when a context is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        n = 3000
+        u = synth.uniform_bytes(n, tag=b"ovr")
+        pts = ctx.points_from_uniform(u)
+        arr, _ = oracle.from_uniform(u)
+        for sc in (synth.scalars(n, tag=b"ovr-s"), synth.small_scalars(n, 1, tag=b"ovr-b"), synth.small_scalars(n, 9, tag=b"ovr-9"),
+                   synth.scalars(1, tag=b"ovr-e") * n):
+            assert ctx.msm(pts, sc) == oracle.msm(sc, arr, n)
+    finally:
+        ctx.close()
