@@ -209,6 +209,26 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
 
 constexpr int SORT_U = 8;
 
+// LDS cursor increment, aggregated when every active lane of the wave asks for the same counter
+// (skewed digits: bit witnesses send a whole tile to one bin / one bucket; 64 lanes hammering
+// one LDS address serialise).  Returns the lane's slot (old counter value + its rank among the
+// wave's active lanes).  Wave-uniform control flow; inactive lanes get 0.
+__device__ __forceinline__ uint32_t lds_claim(uint32_t *ctr, uint32_t key, bool active) {
+    const uint64_t act = __ballot(active);
+    if (!act) return 0u;
+    const int first = __ffsll((unsigned long long)act) - 1;
+    const uint32_t k0 = __shfl(key, first, 64);
+    const uint64_t same = __ballot(active && key == k0);
+    if (same == act) {
+        const int lane = threadIdx.x & 63;
+        uint32_t old = 0;
+        if (lane == first) old = atomicAdd(&ctr[k0], (uint32_t)__popcll(same));
+        old = __shfl(old, first, 64);
+        return old + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&ctr[key], 1u) : 0u;
+}
+
 // bin histogram: bin_counts[bset * NBIN + bin] += entries of this (tile, window, target)
 __global__ void __launch_bounds__(512) k_bin_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ bin_counts, size_t n,
                                                   int W, int NBIN, int lowshift, int tile, int shared) {
@@ -229,7 +249,7 @@ __global__ void __launch_bounds__(512) k_bin_hist(const int16_t *__restrict__ di
         }
 #pragma unroll
         for (int u = 0; u < SORT_U; u++)
-            if (d[u] != 0) atomicAdd(&lds[((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift], 1u);
+            (void)lds_claim(lds, (uint32_t)((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift, d[u] != 0);
     }
     __syncthreads();
     uint32_t *gc = bin_counts + bset * NBIN;
@@ -291,7 +311,7 @@ __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__
         }
 #pragma unroll
         for (int u = 0; u < SORT_U; u++)
-            if (d[u] != 0) atomicAdd(&lds[((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift], 1u);
+            (void)lds_claim(lds, (uint32_t)((d[u] < 0 ? -d[u] : d[u]) - 1) >> lowshift, d[u] != 0);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < NBIN; b += blockDim.x) {
@@ -311,12 +331,10 @@ __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__
         }
 #pragma unroll
         for (int u = 0; u < SORT_U; u++) {
-            if (d[u] != 0) {
-                const size_t i = i0 + (size_t)u * blockDim.x;
-                const uint32_t bk = (uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1u;
-                const uint32_t pos = atomicAdd(&lds[bk >> lowshift], 1u);
-                tmp[pos] = make_uint2((uint32_t)i | wtag | (d[u] < 0 ? 0x80000000u : 0u), bk & lowmask);
-            }
+            const size_t i = i0 + (size_t)u * blockDim.x;
+            const uint32_t bk = (uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1u;
+            const uint32_t pos = lds_claim(lds, bk >> lowshift, d[u] != 0);
+            if (d[u] != 0) tmp[pos] = make_uint2((uint32_t)i | wtag | (d[u] < 0 ? 0x80000000u : 0u), bk & lowmask);
         }
     }
 }
@@ -340,8 +358,7 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ b
             b[u] = i < hi ? tmp[i].y : 0xffffffffu;
         }
 #pragma unroll
-        for (int u = 0; u < SORT_U; u++)
-            if (b[u] != 0xffffffffu) atomicAdd(&cnt[b[u]], 1u);
+        for (int u = 0; u < SORT_U; u++) (void)lds_claim(cnt, b[u], b[u] != 0xffffffffu);
     }
     __syncthreads();
     // exclusive scan of cnt[0..256) (LOWN <= 256; the rest is zero)
@@ -373,8 +390,10 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ b
             it[u] = i < hi ? tmp[i] : make_uint2(0u, 0xffffffffu);
         }
 #pragma unroll
-        for (int u = 0; u < SORT_U; u++)
-            if (it[u].y != 0xffffffffu) entries[atomicAdd(&cur[it[u].y], 1u)] = it[u].x;
+        for (int u = 0; u < SORT_U; u++) {
+            const uint32_t pos = lds_claim(cur, it[u].y, it[u].y != 0xffffffffu);
+            if (it[u].y != 0xffffffffu) entries[pos] = it[u].x;
+        }
     }
 }
 
