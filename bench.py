@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--proofs-per-thread", type=int, default=4)
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "4")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "2")),
                     help="MSM jobs submitted before the oldest is waited for (each on its own stream)")
     args = ap.parse_args()
 
@@ -341,7 +341,7 @@ def main():
             "roofline": {"bound": "valu_int32 (v_mad_u64_u32 issue)", "kernel": "k_accumulate",
                          "achieved": achieved, "peak": VMAD_PEAK_GMACS, "unit": "GMAC/s", "frac": achieved / VMAD_PEAK_GMACS,
                          "kernel_avg_us": acc, "kernel_alone_us": min(alone_us), "frac_alone": MAC_PER_POINT_ACCUMULATE * n / (min(alone_us) * 1e-6) / 1e9 / VMAD_PEAK_GMACS,
-                         "note": "kernel_avg_us is measured in the timed region, where %d MSMs are in flight and share the GPU; kernel_alone_us is the same kernel with the GPU to itself" % args.in_flight,
+                         "note": "kernel_avg_us: timed region, %d MSMs in flight (their accumulate passes run one after another, the other kernels overlap them); kernel_alone_us: the same kernel with the GPU to itself" % args.in_flight,
                          "algorithmic_mac_per_point": MAC_PER_POINT_ACCUMULATE,
                          "executed_mac_per_point": plan["windows"] * 504,
                          "hbm_algorithmic_GBps": BYTES_PER_POINT * n / (acc * 1e-6) / 1e9, "hbm_peak_GBps": 8000.0,

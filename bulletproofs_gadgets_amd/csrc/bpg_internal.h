@@ -112,6 +112,7 @@ struct bpg_lane {
     hipStream_t stream = nullptr;     // setup / codec / scalar-vector kernel stream
     std::vector<bpg_msm_job *> jobs;  // MSM job pool (each job has its own stream)
     float last_acc_us = 0.f, last_total_us = 0.f;
+    bpg_msm_job *acc_gate_job = nullptr;   // job whose accumulate pass was submitted last (its ev[2] gates the next one)
     // bump arena for the R1CS scalar-vector kernels (grown on demand, reused across proofs)
     void *ws = nullptr;
     size_t ws_cap = 0;

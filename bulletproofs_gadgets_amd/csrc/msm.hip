@@ -1009,6 +1009,9 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     // thread -> bucket maps of levels 0 and 1 (level 1 only exists when nlevels > 1)
     hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
                        map0, map1, (uint32_t)NE, pl.ls0, pl.ls1);
+    // Accumulate passes of one lane's jobs run one after another: two of them at once only time-slice the
+    // VALU, while the sort / merge / tail kernels of a later job do overlap usefully with an earlier job's pass.
+    if (lane->acc_gate_job && lane->acc_gate_job != j) BPG_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
     if (nseg > 1)
         hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
@@ -1017,6 +1020,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         hipLaunchKernelGGL((k_accumulate<false>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
                            ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
+    lane->acc_gate_job = j;
     const bool wide = pl.ls1 == 4 && NE <= 32768;          // latency-bound regime: 4 lanes per merge
     for (int r = 1; r < nlevels; r++) {
         const uint32_t *mp = r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr;
