@@ -595,8 +595,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
     const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
     uint32_t cnt = counts[g];
     uint32_t off = ent_off[g];
-    uint32_t lo = rank * (uint32_t)ls0, hi = lo + (uint32_t)ls0;
-    hi = hi < cnt ? hi : cnt;
+    // the bucket's k = ceil(cnt / S0) threads share its entries evenly (sizes differ by at most one): with fixed
+    // S0-entry segments the last one is half empty on average and its lane idles while the wave runs S0 steps
+    const uint32_t k = (cnt + (uint32_t)ls0 - 1) / (uint32_t)ls0;
+    const uint32_t base = cnt / k, rem = cnt - base * k;
+    const uint32_t lo = rank * base + (rank < rem ? rank : rem);
+    const uint32_t hi = lo + base + (rank < rem ? 1u : 0u);
     ge acc;
     ge_identity(acc);
     for (uint32_t e = off + lo; e < off + hi; e++) {
