@@ -348,7 +348,7 @@ def main():
                          "traffic": ACC_TRAFFIC_BYTES_2_20 if args.logn == 20 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(n, 1 << 18)
+            sample = n                      # the whole workload: ~3 s of one core at 2^20
             v, ok, cpu_s = cpu_baseline(ctx, pts, sc, sample)
             line["cpu_baseline"] = {"value": v, "unit": "points/s", "cores": 1, "kind": "port",
                                     "sample": "oracle msm_pippenger_vt (dalek vartime Pippenger, w=8) on the first 2^%d points, %.1f s"
