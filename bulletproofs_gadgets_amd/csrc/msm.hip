@@ -136,9 +136,11 @@ struct sc_map {
 // scalar -> signed c-bit digits.  digits[(t*W + w)*n + i]
 template <int C>
 __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, int16_t *__restrict__ digits,
-                                                size_t n, size_t total, sc_map sm) {
+                                                size_t n, size_t total, sc_map sm, uint32_t *__restrict__ zero, uint32_t nzero) {
     constexpr int W = windows_for(C);
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // clears the sort's bin counters on the way (a separate memset is up to three fill kernels)
+    for (size_t z = gid; z < nzero; z += (size_t)gridDim.x * 256) zero[z] = 0u;
     if (gid >= total) return;
     size_t t = gid / n, i = gid - t * n;
     uint32_t start = 0, off = sm.off[0];
@@ -843,14 +845,16 @@ int grow(void **p, size_t *cap, size_t need) {
 }
 
 template <int C>
-static void launch_digits(hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm) {
+static void launch_digits(hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm,
+                          uint32_t *zero, uint32_t nzero) {
     unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(k_digits<C>, dim3(blocks), dim3(256), 0, s, sc, dg, n, total, sm);
+    hipLaunchKernelGGL(k_digits<C>, dim3(blocks), dim3(256), 0, s, sc, dg, n, total, sm, zero, nzero);
 }
 
-static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm) {
+static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm,
+                            uint32_t *zero, uint32_t nzero) {
     switch (c) {
-#define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total, sm); break;
+#define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total, sm, zero, nzero); break;
         BPG_CASE(2) BPG_CASE(3) BPG_CASE(4) BPG_CASE(5) BPG_CASE(6) BPG_CASE(7) BPG_CASE(8) BPG_CASE(9)
         BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14)
 #undef BPG_CASE
@@ -985,12 +989,11 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
 
     const int shared = fb.c ? 1 : 0;
-    dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap);
     // two-level bucket sort: bins (high bucket bits), then buckets inside each bin
     uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
     uint32_t *bin_counts = map0 + map_words, *bin_fill = bin_counts + NBT, *bin_off = bin_fill + NBT;
     uint2 *tmp = (uint2 *)j->d_tmp;
-    BPG_CHECK_HIP(hipMemsetAsync(bin_counts, 0, 2 * NBT * sizeof(uint32_t), s));
+    dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap, bin_counts, (uint32_t)(2 * NBT));
     dim3 tgrid(pl.ntiles, pl.W, T);
     const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
     hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile,
