@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# More than two MSMs in flight need more hardware queues than HIP's default of 4: streams that share a queue
+# run in submission order, and a stream parked on the accumulate gate then holds up the others behind it.
+# (read by the HIP runtime when it starts, so set before anything loads it)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -161,7 +166,7 @@ def main():
     ap.add_argument("--proofs-per-thread", type=int, default=4)
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "2")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "4")),
                     help="MSM jobs submitted before the oldest is waited for (each on its own stream)")
     args = ap.parse_args()
 

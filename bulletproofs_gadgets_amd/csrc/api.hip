@@ -271,6 +271,7 @@ int bpg_init(int device_id, bpg_ctx **out) {
     if (const char *s = getenv("BPG_MSM_TILE")) ctx->tune.tile = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS1")) ctx->tune.ls1 = atoi(s);
+    if (const char *s = getenv("BPG_MSM_SORT_CHUNK")) ctx->tune.sort_chunk = atoi(s);
     *out = ctx;
     return BPG_OK;
 }

@@ -55,9 +55,11 @@ struct msm_plan {
     int outs;         // points per (target, window) = c  (total + c-1 bit sums)
     int nbin;         // bins per bucket set in the two-level sort (NB = nbin << lowshift)
     int lowshift;     // log2(buckets per bin)
+    int sort_chunk;   // items of one bin that one block of the level-2 sort handles
 };
 struct msm_tuning {
     int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
+    int sort_chunk = 0;                      // 0 = automatic (BPG_MSM_SORT_CHUNK)
 };
 msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c = 0, float density = 1.f, int resident_lanes = 262144);
 // fixed-base (precomputed 2^(c w) multiples) geometry for a table of `points` generators

@@ -261,32 +261,57 @@ __global__ void __launch_bounds__(512) k_bin_hist(const int16_t *__restrict__ di
     }
 }
 
-// exclusive scan of the bin counts (one block; at most a few thousand bins)
-__global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t *__restrict__ bin_counts, uint32_t *__restrict__ bin_off, uint32_t nbt) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t running;
-    if (threadIdx.x == 0) running = 0;
-    __syncthreads();
+// exclusive scans of the bin counts and of the bins' chunk counts (one block; at most a few thousand
+// bins).  Level 2 works on chunks of at most CH items of one bin, so a bin that a skewed digit
+// distribution filled (bit witnesses: half a window's entries in one bin) is spread over many blocks.
+__global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t *__restrict__ bin_counts, uint32_t *__restrict__ bin_off,
+                                                   uint32_t *__restrict__ chunk_off, uint32_t nbt, uint32_t CH) {
+    __shared__ uint32_t wsum[16], wsumc[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t start = 0; start < nbt; start += 1024) {
-        uint32_t i = start + threadIdx.x;
-        uint32_t mine = i < nbt ? bin_counts[i] : 0u;
-        uint32_t x = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t y = __shfl_up(x, o, 64);
-            if (lane >= o) x += y;
+    // thread i owns elements [i * per, (i + 1) * per)
+    const uint32_t per = (nbt + 1023u) / 1024u, first = threadIdx.x * per;
+    uint32_t mine = 0, minec = 0;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = first + k;
+        if (i < nbt) {
+            const uint32_t v = bin_counts[i];
+            mine += v;
+            minec += v > CH ? (v + CH - 1) / CH : 1u;      // an empty bin keeps one chunk: it writes the zero counts
         }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        uint32_t wbase = running;
-        for (int k = 0; k < wave; k++) wbase += wsum[k];
-        if (i < nbt) bin_off[i] = wbase + x - mine;
-        __syncthreads();
-        if (threadIdx.x == 1023) running = wbase + x;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) bin_off[nbt] = running;
+    uint32_t x = mine, xc = minec;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o, 64), yc = __shfl_up(xc, o, 64);
+        if (lane >= o) {
+            x += y;
+            xc += yc;
+        }
+    }
+    if (lane == 63) {
+        wsum[wave] = x;
+        wsumc[wave] = xc;
+    }
+    __syncthreads();
+    uint32_t run = x - mine, runc = xc - minec;
+    for (int k = 0; k < wave; k++) {
+        run += wsum[k];
+        runc += wsumc[k];
+    }
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = first + k;
+        if (i < nbt) {
+            const uint32_t v = bin_counts[i];
+            bin_off[i] = run;
+            chunk_off[i] = runc;
+            run += v;
+            runc += v > CH ? (v + CH - 1) / CH : 1u;
+        }
+    }
+    if (threadIdx.x == 1023) {                             // its running sums are the totals (elements past nbt add nothing)
+        bin_off[nbt] = run;
+        chunk_off[nbt] = runc;
+    }
 }
 
 // level 1: entries -> bins.  tmp[pos] = (entry, bucket number within the bin); entry = scalar
@@ -341,14 +366,38 @@ __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__
     }
 }
 
-// level 2: one block per bin.  counts[g], ent_off[g] for the bin's LOWN buckets; entries sorted by bucket.
-__global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ bin_off, const uint2 *__restrict__ tmp,
-                                                  uint32_t *__restrict__ counts, uint32_t *__restrict__ ent_off,
-                                                  uint32_t *__restrict__ entries, int LOWN) {
+// level 2, chunk c -> its bin and its items [lo, hi) of tmp.  false: c is past the last chunk.
+__device__ __forceinline__ bool chunk_range(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
+                                            uint32_t nbt, uint32_t CH, uint32_t c, uint32_t &bin, uint32_t &lo, uint32_t &hi) {
+    const uint32_t nch = chunk_off[nbt];
+    if (c >= nch) return false;
+    uint32_t a = c, b = nbt;                               // every bin a single chunk (uniform digits): chunk c is bin c
+    if (nch != nbt) {
+        a = 0;                                             // chunk_off[a] <= c < chunk_off[b]
+        while (b - a > 1) {
+            const uint32_t m = (a + b) >> 1;
+            if (chunk_off[m] <= c) a = m;
+            else b = m;
+        }
+    }
+    bin = a;
+    lo = bin_off[a] + (c - chunk_off[a]) * CH;
+    const uint32_t end = bin_off[a + 1];
+    hi = end - lo > CH ? lo + CH : end;
+    return true;
+}
+
+// level 2a: one block per chunk counts the chunk's items per bucket of its bin: chunk_hist[c][LOWN].
+// A bin that is a single chunk (every bin, when the digits are uniform) is finished here: counts[g],
+// ent_off[g], entries sorted by bucket; 2b and 2c then skip it.
+__global__ void __launch_bounds__(256) k_chunk_count(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
+                                                     const uint2 *__restrict__ tmp, uint32_t *__restrict__ chunk_hist,
+                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ ent_off,
+                                                     uint32_t *__restrict__ entries, uint32_t nbt, uint32_t CH, int LOWN) {
     __shared__ uint32_t cnt[256], cur[256];
     __shared__ uint32_t wsum[4];
-    const uint32_t bin = blockIdx.x;
-    const uint32_t lo = bin_off[bin], hi = bin_off[bin + 1];
+    uint32_t bin, lo, hi;
+    if (!chunk_range(bin_off, chunk_off, nbt, CH, blockIdx.x, bin, lo, hi)) return;
     const int tid = threadIdx.x;
     cnt[tid] = 0;
     __syncthreads();
@@ -363,6 +412,10 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ b
         for (int u = 0; u < SORT_U; u++) (void)lds_claim(cnt, b[u], b[u] != 0xffffffffu);
     }
     __syncthreads();
+    if (chunk_off[bin + 1] - chunk_off[bin] != 1u) {       // block-uniform
+        if (tid < LOWN) chunk_hist[(size_t)blockIdx.x * LOWN + tid] = cnt[tid];
+        return;
+    }
     // exclusive scan of cnt[0..256) (LOWN <= 256; the rest is zero)
     const uint32_t mine = cnt[tid];
     uint32_t x = mine;
@@ -396,6 +449,83 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t *__restrict__ b
             const uint32_t pos = lds_claim(cur, it[u].y, it[u].y != 0xffffffffu);
             if (it[u].y != 0xffffffffu) entries[pos] = it[u].x;
         }
+    }
+}
+
+// level 2b: one block per bin.  counts[g], ent_off[g] for the bin's LOWN buckets; chunk_hist becomes
+// each chunk's first slot within the bucket (exclusive running sum over the bin's chunks).
+__global__ void __launch_bounds__(256) k_chunk_offsets(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
+                                                       uint32_t *__restrict__ chunk_hist, uint32_t *__restrict__ counts,
+                                                       uint32_t *__restrict__ ent_off, uint32_t nbt, int LOWN) {
+    __shared__ uint32_t wsum[4];
+    if (chunk_off[nbt] == nbt) return;                     // every bin is a single chunk: 2a did it all
+    const int tid = threadIdx.x;
+    for (uint32_t bin = blockIdx.x; bin < nbt; bin += gridDim.x) {
+        const uint32_t lo = bin_off[bin], c0 = chunk_off[bin], c1 = chunk_off[bin + 1];
+        if (c1 - c0 == 1u) continue;
+        uint32_t mine = 0;
+        if (tid < LOWN) {
+            for (uint32_t c = c0; c < c1; c += SORT_U) {
+                uint32_t v[SORT_U];
+#pragma unroll
+                for (int u = 0; u < SORT_U; u++) v[u] = c + u < c1 ? chunk_hist[(size_t)(c + u) * LOWN + tid] : 0u;
+#pragma unroll
+                for (int u = 0; u < SORT_U; u++) {
+                    if (c + u < c1) chunk_hist[(size_t)(c + u) * LOWN + tid] = mine;
+                    mine += v[u];
+                }
+            }
+        }
+        // exclusive scan over the bin's buckets (LOWN <= 256; the rest is zero)
+        uint32_t x = mine;
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int k = 0; k < wave; k++) wbase += wsum[k];
+        if (tid < LOWN) {
+            const size_t g = (size_t)bin * LOWN + tid;
+            counts[g] = mine;
+            ent_off[g] = lo + wbase + x - mine;
+        }
+        __syncthreads();                                   // wsum is reused
+    }
+}
+
+// level 2c: one block per chunk places the chunk's entries: entries sorted by bucket
+__global__ void __launch_bounds__(256) k_chunk_place(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
+                                                     const uint2 *__restrict__ tmp, const uint32_t *__restrict__ chunk_hist,
+                                                     const uint32_t *__restrict__ ent_off, uint32_t *__restrict__ entries,
+                                                     uint32_t nbt, uint32_t CH, int LOWN) {
+    __shared__ uint32_t cur[256];
+    const uint32_t nch = chunk_off[nbt];
+    if (nch == nbt) return;                                // every bin is a single chunk: 2a did it all
+    const int tid = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        uint32_t bin, lo, hi;
+        (void)chunk_range(bin_off, chunk_off, nbt, CH, c, bin, lo, hi);
+        if (chunk_off[bin + 1] - chunk_off[bin] == 1u) continue;
+        cur[tid] = tid < LOWN ? ent_off[(size_t)bin * LOWN + tid] + chunk_hist[(size_t)c * LOWN + tid] : 0u;
+        __syncthreads();
+        for (uint32_t i0 = lo + tid; i0 < hi; i0 += 256u * SORT_U) {
+            uint2 it[SORT_U];
+#pragma unroll
+            for (int u = 0; u < SORT_U; u++) {
+                const uint32_t i = i0 + 256u * u;
+                it[u] = i < hi ? tmp[i] : make_uint2(0u, 0xffffffffu);
+            }
+#pragma unroll
+            for (int u = 0; u < SORT_U; u++) {
+                const uint32_t pos = lds_claim(cur, it[u].y, it[u].y != 0xffffffffu);
+                if (it[u].y != 0xffffffffu) entries[pos] = it[u].x;
+            }
+        }
+        __syncthreads();                                   // cur is reused
     }
 }
 
@@ -827,6 +957,7 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float d
         pl.lowshift = 0;
         while ((nbin << pl.lowshift) < pl.NB) pl.lowshift++;
     }
+    pl.sort_chunk = (tune.sort_chunk >= 256 && tune.sort_chunk <= (1 << 20)) ? tune.sort_chunk : 12288;
     pl.chunk = pl.NB < 256 ? pl.NB : 256;
     pl.nchunks = pl.NB / pl.chunk;
     pl.outs = c;
@@ -971,8 +1102,11 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
     const size_t map_words = cap_lv[0] + (nlevels > 1 ? cap_lv[1] : 0);
     const size_t NBT = (size_t)T * pl.Wb * pl.nbin;        // bins
+    const uint32_t CH = (uint32_t)pl.sort_chunk;          // items per level-2 block
+    const int LOWN = pl.NB / pl.nbin;                      // buckets per bin
+    const size_t NCH = M / CH + NBT;                       // upper bound on chunks: sum of max(1, ceil(cnt / CH))
     if ((rc = grow((void **)&j->d_counts, &j->cap_counts,
-                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 3 * NBT + 16) * sizeof(uint32_t))))
+                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 4 * NBT + NCH * (size_t)LOWN + 16) * sizeof(uint32_t))))
         return rc;
     if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, M * sizeof(uint2) + 64))) return rc;    // level-1 output: (entry, bucket in bin)
     if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
@@ -992,17 +1126,23 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     // two-level bucket sort: bins (high bucket bits), then buckets inside each bin
     uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
     uint32_t *bin_counts = map0 + map_words, *bin_fill = bin_counts + NBT, *bin_off = bin_fill + NBT;
+    uint32_t *chunk_off = bin_off + NBT + 1, *chunk_hist = chunk_off + NBT + 1;
     uint2 *tmp = (uint2 *)j->d_tmp;
     dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap, bin_counts, (uint32_t)(2 * NBT));
     dim3 tgrid(pl.ntiles, pl.W, T);
     const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
     hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile,
                        shared);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, (uint32_t)NBT);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, chunk_off, (uint32_t)NBT, CH);
     hipLaunchKernelGGL(k_bin_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, pl.W,
                        pl.nbin, pl.lowshift, pl.tile, shared);
-    hipLaunchKernelGGL(k_bin_sort, dim3((unsigned)NBT), dim3(256), 0, s, bin_off, tmp, counts, ent_off,
-                       j->d_entries, pl.NB / pl.nbin);
+    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
+                       j->d_entries, (uint32_t)NBT, CH, LOWN);
+    // (2b and 2c have work only when some bin is larger than a chunk: modest grids that stride)
+    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(NBT < 512 ? NBT : 512)), dim3(256), 0, s, bin_off, chunk_off, chunk_hist, counts, ent_off,
+                       (uint32_t)NBT, LOWN);
+    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(NCH < 2048 ? NCH : 2048)), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, ent_off,
+                       j->d_entries, (uint32_t)NBT, CH, LOWN);
     // thread offsets of every pass (levels 0..R), two launches
     hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, pl.ls0,
                        pl.ls1);

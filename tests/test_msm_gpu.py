@@ -183,10 +183,11 @@ def test_msm_full_size_properties(gpu_ctx, logn):
 
 @pytest.mark.parametrize("env", [{"BPG_MSM_LS0": "1"}, {"BPG_MSM_LS0": "5"}, {"BPG_MSM_LS0": "23", "BPG_MSM_LS1": "3"},
                                  {"BPG_MSM_C": "9", "BPG_MSM_TILE": "512"}, {"BPG_MSM_C": "12", "BPG_MSM_LS0": "64"},
-                                 {"BPG_MSM_C": "6", "BPG_MSM_LS1": "2"}])
+                                 {"BPG_MSM_C": "6", "BPG_MSM_LS1": "2"}, {"BPG_MSM_SORT_CHUNK": "256"},
+                                 {"BPG_MSM_C": "12", "BPG_MSM_SORT_CHUNK": "300"}])
 def test_msm_planner_overrides(oracle, env):
     """every geometry the planner can be pushed into (segment size S0 not a power of two, narrow and wide
-    merge passes, deep merge trees, small tiles, one and many buckets per bin) gives the oracle's bytes,
+    merge passes, deep merge trees, small tiles, one and many buckets per bin, many level-2 chunks per bin) gives the oracle's bytes,
     on uniform and on skewed scalars"""
     import os
     import bulletproofs_gadgets_amd as bpg
