@@ -26,7 +26,7 @@ import time
 # More than two MSMs in flight need more hardware queues than HIP's default of 4: streams that share a queue
 # run in submission order, and a stream parked on the accumulate gate then holds up the others behind it.
 # (read by the HIP runtime when it starts, so set before anything loads it)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("BPG_BENCH_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
