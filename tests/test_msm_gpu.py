@@ -181,6 +181,35 @@ def test_msm_full_size_properties(gpu_ctx, logn):
     assert got == gpu_ctx.msm(sel, small)
 
 
+def test_msm_full_size_skewed(gpu_ctx):
+    """2^20 points with the digit distributions that fill single bins and buckets (the level-2 sort then runs
+    many chunks per bin, the merge passes run deep): all scalars equal, all ones, random bits.
+    MSM(s, s, ..., s) == s * MSM(1, ..., 1), the right side through a one-point MSM (an oracle-checked size);
+    MSM(bits) + MSM(1 - bits) == MSM(ones)."""
+    import numpy as np
+    from bulletproofs_gadgets_amd import _native
+    n = 1 << 20
+    pts = gpu_ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"skew20"))
+    one = (1).to_bytes(32, "little")
+    ones = gpu_ctx.alloc(32 * n).upload(one * n)
+    q_part = gpu_ctx.msm_submit(pts, ones.ptr, n).wait_partial()
+    q = _native.combine_partials(q_part)
+    assert q != bytes(32)
+    s = synth.scalars(1, tag=b"skew-s")
+    eq = gpu_ctx.alloc(32 * n).upload(s * n)
+    got = gpu_ctx.msm_submit(pts, eq.ptr, n).wait()
+    assert got == gpu_ctx.msm(gpu_ctx.points_from_compressed(q), s)
+    rng = np.random.default_rng(20)
+    bits = rng.integers(0, 2, size=n, dtype=np.uint8)
+    b = np.zeros((n, 32), dtype=np.uint8)
+    b[:, 0] = bits
+    nb = np.zeros((n, 32), dtype=np.uint8)
+    nb[:, 0] = 1 - bits
+    pb = gpu_ctx.msm_submit(pts, gpu_ctx.alloc(32 * n).upload(b.tobytes()).ptr, n).wait_partial()
+    pnb = gpu_ctx.msm_submit(pts, gpu_ctx.alloc(32 * n).upload(nb.tobytes()).ptr, n).wait_partial()
+    assert _native.combine_partials(pb + pnb) == q
+
+
 @pytest.mark.parametrize("env", [{"BPG_MSM_LS0": "1"}, {"BPG_MSM_LS0": "5"}, {"BPG_MSM_LS0": "23", "BPG_MSM_LS1": "3"},
                                  {"BPG_MSM_C": "9", "BPG_MSM_TILE": "512"}, {"BPG_MSM_C": "12", "BPG_MSM_LS0": "64"},
                                  {"BPG_MSM_C": "6", "BPG_MSM_LS1": "2"}, {"BPG_MSM_SORT_CHUNK": "256"},
