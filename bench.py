@@ -85,10 +85,11 @@ def proof_statement_bytes(nbits):
     return base, bits, expected, vals, randomness
 
 
-def proof_bench(ctx, rank, threads, per_thread, nbits=PROOF_BITS):
-    """R1CS proofs at 2^16 multipliers on this rank's GPU: `threads` host threads, one proof per
-    thread at a time, each on its own stream against one shared generator table.  Returns
-    (proofs, seconds prove-only, seconds prove+verify, single-proof latencies in ms, a proof)."""
+def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
+    """R1CS proofs at 2^16 multipliers on this rank's GPU: `threads` host threads, each on its own
+    stream against one shared generator table, proving `per_call` statements per bpg_prover_prove_many
+    call (their blinding RNGs advance in lock-step; the GPU part is one proof at a time per thread).
+    Returns (proofs, seconds prove-only, seconds prove+verify, single-proof latencies in ms, a proof)."""
     import threading
     from bulletproofs_gadgets_amd import r1cs as g
     base, bits, expected, vals, randomness = proof_statement_bytes(nbits)
@@ -108,7 +109,26 @@ def proof_bench(ctx, rank, threads, per_thread, nbits=PROOF_BITS):
             assert v.verify(proof, None, gens, ext_v)
         return proof
 
+    def many(tags, verify):
+        ps, meta = [], []
+        for tag in tags:
+            bl, ext_p, ext_v = randomness(tag)
+            p = g.Prover(gens, b"ScalarMul")
+            comms, vars_ = p.commit_batch_raw(vals, bl)
+            E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
+            ps.append(p)
+            meta.append((comms, ext_p, ext_v))
+        proofs = g.Prover.prove_many(ps, b"".join(m[1] for m in meta))
+        del ps
+        if verify:
+            for (comms, _, ext_v), proof in zip(meta, proofs):
+                v = g.Verifier(b"ScalarMul")
+                E.scalar_mul(E.from_point(base), v.commit_batch_raw(comms.raw), v).equal(E.from_point(expected), v)
+                assert v.verify(proof, None, gens, ext_v)
+        return proofs
+
     first = one(b"parity", True)                       # also the warm-up of the main thread's lane
+    assert many([b"parity", b"parity2"], False)[0].to_bytes() == first.to_bytes()
     lat = []
     for verify in (False, True):
         t0 = time.perf_counter()
@@ -120,8 +140,10 @@ def proof_bench(ctx, rank, threads, per_thread, nbits=PROOF_BITS):
 
         def worker(tid, warm):
             try:
-                for r in range(1 if warm else per_thread):
-                    one(b"%d/%d/%d" % (rank, tid, r), verify)
+                if warm:
+                    one(b"%d/%d/w" % (rank, tid), verify)
+                for r0 in range(0, 0 if warm else per_thread, per_call):
+                    many([b"%d/%d/%d" % (rank, tid, r) for r in range(r0, min(per_thread, r0 + per_call))], verify)
             except Exception as e:  # noqa: BLE001
                 errs.append(repr(e))
         for warm in (True, False):                     # first pass: every thread's lane allocates its workspace
@@ -163,7 +185,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
     ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "24")))
-    ap.add_argument("--proofs-per-thread", type=int, default=4)
+    ap.add_argument("--proofs-per-thread", type=int, default=8)
+    ap.add_argument("--proofs-per-call", type=int, default=8, help="statements per bpg_prover_prove_many call (1: plain prove calls)")
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "4")),
@@ -254,7 +277,7 @@ def main():
     proofs = None
     if not args.no_proofs:
         barrier()
-        cnt, s_prove, s_pv, lat, first_proof = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread)
+        cnt, s_prove, s_pv, lat, first_proof = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread, max(1, args.proofs_per_call))
         barrier()
         if world > 1:
             tt = torch.tensor([s_prove, s_pv], dtype=torch.float64, device=cdev)
@@ -263,7 +286,7 @@ def main():
         proofs = {"metric": "R1CS proofs/s at 2^16 multipliers", "unit": "proofs/s",
                   "prove": world * cnt / s_prove, "prove_and_verify": world * cnt / s_pv,
                   "multipliers": 27 * PROOF_BITS + 4, "proof_bytes": len(first_proof.to_bytes()),
-                  "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt,
+                  "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt, "proofs_per_call": args.proofs_per_call,
                   "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
                               "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}

@@ -82,6 +82,7 @@ def lib():
         "bpg_prover_commit": (ci, [vp, cp, cp, vp, u64p]),
         "bpg_prover_commit_batch": (ci, [vp, cp, cp, sz, vp, u64p]),
         "bpg_prover_prove": (ci, [vp, RNG_FN, vp, vp, sz, psz]),
+        "bpg_prover_prove_many": (ci, [vp, sz, RNG_FN, vp, vp, sz, psz]),
         "bpg_prover_stats": (ci, [vp, psz, psz]),
         "bpg_prover_timing": (ci, [vp, dp]),
         "bpg_verifier_new": (ci, [cp, sz, pvp]),

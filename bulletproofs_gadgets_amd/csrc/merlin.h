@@ -10,6 +10,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "sc25519.h"
 
@@ -231,6 +234,69 @@ inline void keccak_f1600(uint64_t s[25]) { keccak_f1600_generic(s); }
 #endif
 #undef BPG_KECCAK_BODY
 
+// ---- eight Keccak-f[1600] states at once (AVX-512: lane l of every 512-bit word belongs to state l).
+// Used where eight independent Keccak chains advance in lock-step (the blinding RNGs of eight proofs).
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) inline void keccak_f1600_x8_avx512(uint64_t st[25][8]) {
+    __m512i a[25], b[25], c[5], d[5];
+    for (int i = 0; i < 25; i++) a[i] = _mm512_loadu_si512((const void *)st[i]);
+    for (int round = 0; round < 24; round++) {
+        for (int x = 0; x < 5; x++)
+            c[x] = _mm512_ternarylogic_epi64(_mm512_ternarylogic_epi64(a[x], a[x + 5], a[x + 10], 0x96), a[x + 15], a[x + 20], 0x96);
+        for (int x = 0; x < 5; x++) d[x] = _mm512_xor_si512(c[(x + 4) % 5], _mm512_rol_epi64(c[(x + 1) % 5], 1));
+        // theta, rho, pi: b[y + 5 ((2x + 3y) mod 5)] = rol(a[x + 5y] ^ d[x], rho[x + 5y])
+        b[0] = _mm512_xor_si512(a[0], d[0]);
+        b[10] = _mm512_rol_epi64(_mm512_xor_si512(a[1], d[1]), 1);
+        b[20] = _mm512_rol_epi64(_mm512_xor_si512(a[2], d[2]), 62);
+        b[5] = _mm512_rol_epi64(_mm512_xor_si512(a[3], d[3]), 28);
+        b[15] = _mm512_rol_epi64(_mm512_xor_si512(a[4], d[4]), 27);
+        b[16] = _mm512_rol_epi64(_mm512_xor_si512(a[5], d[0]), 36);
+        b[1] = _mm512_rol_epi64(_mm512_xor_si512(a[6], d[1]), 44);
+        b[11] = _mm512_rol_epi64(_mm512_xor_si512(a[7], d[2]), 6);
+        b[21] = _mm512_rol_epi64(_mm512_xor_si512(a[8], d[3]), 55);
+        b[6] = _mm512_rol_epi64(_mm512_xor_si512(a[9], d[4]), 20);
+        b[7] = _mm512_rol_epi64(_mm512_xor_si512(a[10], d[0]), 3);
+        b[17] = _mm512_rol_epi64(_mm512_xor_si512(a[11], d[1]), 10);
+        b[2] = _mm512_rol_epi64(_mm512_xor_si512(a[12], d[2]), 43);
+        b[12] = _mm512_rol_epi64(_mm512_xor_si512(a[13], d[3]), 25);
+        b[22] = _mm512_rol_epi64(_mm512_xor_si512(a[14], d[4]), 39);
+        b[23] = _mm512_rol_epi64(_mm512_xor_si512(a[15], d[0]), 41);
+        b[8] = _mm512_rol_epi64(_mm512_xor_si512(a[16], d[1]), 45);
+        b[18] = _mm512_rol_epi64(_mm512_xor_si512(a[17], d[2]), 15);
+        b[3] = _mm512_rol_epi64(_mm512_xor_si512(a[18], d[3]), 21);
+        b[13] = _mm512_rol_epi64(_mm512_xor_si512(a[19], d[4]), 8);
+        b[14] = _mm512_rol_epi64(_mm512_xor_si512(a[20], d[0]), 18);
+        b[24] = _mm512_rol_epi64(_mm512_xor_si512(a[21], d[1]), 2);
+        b[9] = _mm512_rol_epi64(_mm512_xor_si512(a[22], d[2]), 61);
+        b[19] = _mm512_rol_epi64(_mm512_xor_si512(a[23], d[3]), 56);
+        b[4] = _mm512_rol_epi64(_mm512_xor_si512(a[24], d[4]), 14);
+        for (int y = 0; y < 25; y += 5)
+            for (int x = 0; x < 5; x++)
+                a[y + x] = _mm512_ternarylogic_epi64(b[y + x], b[y + (x + 1) % 5], b[y + (x + 2) % 5], 0xD2);   // b ^ (~b' & b'')
+        a[0] = _mm512_xor_si512(a[0], _mm512_set1_epi64((long long)KECCAK_RC[round]));
+    }
+    for (int i = 0; i < 25; i++) _mm512_storeu_si512((void *)st[i], a[i]);
+}
+inline bool keccak_have_avx512() {
+    static const bool have = __builtin_cpu_supports("avx512f");
+    return have;
+}
+#endif
+inline void keccak_f1600_x8(uint64_t st[25][8]) {
+#if defined(__x86_64__)
+    if (keccak_have_avx512()) {
+        keccak_f1600_x8_avx512(st);
+        return;
+    }
+#endif
+    for (int l = 0; l < 8; l++) {
+        uint64_t s[25];
+        for (int i = 0; i < 25; i++) s[i] = st[i][l];
+        keccak_f1600(s);
+        for (int i = 0; i < 25; i++) st[i][l] = s[i];
+    }
+}
+
 // Keccak sponge with byte-granular absorb / squeeze (SHAKE256: rate 136, pad 0x1f; SHA3-512: rate 72, pad 0x06)
 class KeccakSponge {
   public:
@@ -320,6 +386,7 @@ class Strobe128 {
     }
 
   private:
+    friend class TranscriptRngLanes8;
     static constexpr uint8_t R = 166;
     static constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_M = 16, FLAG_K = 32;
     uint8_t *bytes() { return (uint8_t *)st_; }
@@ -396,7 +463,109 @@ class TranscriptRng {
     }
 
   private:
+    friend class TranscriptRngLanes8;
     Strobe128 s_;
+};
+
+// Eight TranscriptRngs advanced in lock-step.  Scalar::random is meta-AD(len) + PRF(64): one Keccak-f per
+// draw, a chain that cannot be split inside one proof -- but the chains of different proofs are independent,
+// and provers of the same circuit are at the same STROBE position, so eight of them share every byte
+// position, operation header and padding and differ only in their 200 state bytes.  The states are kept
+// word-interleaved (st_[word][lane]) and permuted by keccak_f1600_x8.
+// Each lane produces exactly the bytes its own TranscriptRng would have produced.
+class TranscriptRngLanes8 {
+  public:
+    // false (nothing loaded) unless all eight are at the same position of the same operation
+    bool load(TranscriptRng *const r[8]) {
+        const Strobe128 &s0 = r[0]->s_;
+        for (int l = 1; l < 8; l++) {
+            const Strobe128 &sl = r[l]->s_;
+            if (sl.pos_ != s0.pos_ || sl.pos_begin_ != s0.pos_begin_ || sl.cur_flags_ != s0.cur_flags_) return false;
+        }
+        for (int l = 0; l < 8; l++)
+            for (int i = 0; i < 25; i++) st_[i][l] = r[l]->s_.st_[i];
+        pos_ = s0.pos_;
+        pos_begin_ = s0.pos_begin_;
+        cur_flags_ = s0.cur_flags_;
+        return true;
+    }
+    // write lanes [0, count) back
+    void store(TranscriptRng *const r[8], int count) {
+        for (int l = 0; l < count; l++) {
+            Strobe128 &sl = r[l]->s_;
+            for (int i = 0; i < 25; i++) sl.st_[i] = st_[i][l];
+            sl.pos_ = pos_;
+            sl.pos_begin_ = pos_begin_;
+            sl.cur_flags_ = cur_flags_;
+        }
+    }
+    // TranscriptRng::fill_bytes(64) on every lane
+    void fill64(uint8_t out[8][64]) {
+        uint8_t len[4];
+        le32(len, 64);
+        begin_op(Strobe128::FLAG_M | Strobe128::FLAG_A);
+        absorb(len, 4);
+        begin_op(Strobe128::FLAG_I | Strobe128::FLAG_A | Strobe128::FLAG_C);
+        if (pos_ == 0) {                                   // always: the PRF's begin_op ran the permutation
+            for (int w = 0; w < 8; w++)
+                for (int l = 0; l < 8; l++) {
+                    memcpy(out[l] + 8 * w, &st_[w][l], 8);
+                    st_[w][l] = 0;
+                }
+            pos_ = 64;
+            return;
+        }
+        for (int i = 0; i < 64; i++) {
+            for (int l = 0; l < 8; l++) {
+                uint8_t *b = (uint8_t *)&st_[pos_ >> 3][l] + (pos_ & 7);
+                out[l][i] = *b;
+                *b = 0;
+            }
+            if (++pos_ == R) run_f();
+        }
+    }
+    // Scalar::random on every lane
+    void scalars(sc out[8]) {
+        uint8_t buf[8][64];
+        fill64(buf);
+        for (int l = 0; l < 8; l++) {
+            sc lo, hi;
+            sc_frombytes(lo, buf[l]);
+            sc_frombytes(hi, buf[l] + 32);
+            sc_reduce512(out[l], lo, hi);
+        }
+    }
+
+  private:
+    static constexpr uint8_t R = 166;
+    // the same byte into every lane's state
+    void xor_byte(unsigned p, uint8_t v) {
+        const uint64_t m = (uint64_t)v << (8 * (p & 7));
+        for (int l = 0; l < 8; l++) st_[p >> 3][l] ^= m;
+    }
+    void run_f() {
+        xor_byte(pos_, pos_begin_);
+        xor_byte(pos_ + 1u, 0x04);
+        xor_byte(R + 1u, 0x80);
+        keccak_f1600_x8(st_);
+        pos_ = 0;
+        pos_begin_ = 0;
+    }
+    void absorb(const uint8_t *d, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            xor_byte(pos_, d[i]);
+            if (++pos_ == R) run_f();
+        }
+    }
+    void begin_op(uint8_t flags) {
+        const uint8_t hdr[2] = {pos_begin_, flags};
+        pos_begin_ = pos_ + 1;
+        cur_flags_ = flags;
+        absorb(hdr, 2);
+        if ((flags & (Strobe128::FLAG_C | Strobe128::FLAG_K)) && pos_ != 0) run_f();
+    }
+    alignas(64) uint64_t st_[25][8];
+    uint8_t pos_ = 0, pos_begin_ = 0, cur_flags_ = 0;
 };
 
 // merlin::Transcript + bulletproofs::transcript::TranscriptProtocol

@@ -257,16 +257,29 @@ class Prover : public ConstraintSystem {
     Scalar eval(const LinearCombination &lc) const;
     // Prover::prove(bp_gens); returns BPG_OK or a negative BPG_E* code
     int prove(rng_fill_fn rng, void *rng_user, R1CSProof &out);
+    // k proofs by one host thread: byte for byte what k prove() calls in this order give (the external RNG is
+    // asked in the same order), but the blinding RNGs of up to eight provers of one circuit shape are drawn in
+    // lock-step (TranscriptRngLanes8), which is where most of a proof's host time goes.
+    static int prove_many(Prover *const *provers, size_t k, rng_fill_fn rng, void *rng_user, R1CSProof *out);
     size_t num_multipliers() const { return a_L_.size(); }
     size_t num_constraints() const { return cs_.num_constraints; }
     Transcript &transcript() { return tr_; }
     struct Timing { double rng_ms = 0, commit_ms = 0, poly_ms = 0, ipp_ms = 0, total_ms = 0; } timing;
 
   private:
+    // prove() in three steps: transcript RNG set-up, blinding draws (the host's long Keccak chain), the rest
+    int prove_begin(rng_fill_fn rng, void *rng_user);
+    void draw_blindings();
+    int prove_finish(R1CSProof &out);
     Gens *gens_;
     Transcript tr_;
     ConstraintStore cs_;
     std::vector<sc> a_L_, a_R_, a_O_, v_, v_blinding_;
+    // between prove_begin and prove_finish
+    std::unique_ptr<TranscriptRng> rng_;
+    sc i_bl_, o_bl_, s_bl_;
+    std::vector<sc> s_L_, s_R_;
+    double t_start_ = 0;
 };
 
 // scalars of one proof's verification equation (see Verifier::prepare)

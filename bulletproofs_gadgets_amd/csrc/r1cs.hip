@@ -841,34 +841,106 @@ static inline size_t next_pow2(size_t n) {
 }
 
 int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
-    const double t_start = now_ms();
+    int rc = prove_begin(rng_fn, rng_user);
+    if (rc) return rc;
+    draw_blindings();
+    return prove_finish(P);
+}
+
+// ---- transcript RNG (host, sequential Keccak)
+int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
+    t_start_ = now_ms();
+    const size_t n = a_L_.size(), m = v_.size();
+    if (gens_->capacity < next_pow2(n ? n : 1)) return BPG_EGENS;
+    tr_.append_u64("m", m);
+    rng_.reset(new TranscriptRng(tr_.build_rng()));
+    for (size_t i = 0; i < m; i++) {
+        uint8_t b[32];
+        sc_tobytes(b, v_blinding_[i]);
+        rng_->rekey_with_witness_bytes("v_blinding", b, 32);
+    }
+    uint8_t ext[32];
+    rng_fn(rng_user, ext, 32);
+    rng_->finalize(ext);
+    return BPG_OK;
+}
+
+void Prover::draw_blindings() {
+    const double t0 = now_ms();
+    const size_t n = a_L_.size();
+    i_bl_ = rng_->scalar();
+    o_bl_ = rng_->scalar();
+    s_bl_ = rng_->scalar();
+    s_L_.resize(n);
+    s_R_.resize(n);
+    for (size_t i = 0; i < n; i++) s_L_[i] = rng_->scalar();
+    for (size_t i = 0; i < n; i++) s_R_[i] = rng_->scalar();
+    timing.rng_ms = now_ms() - t0;
+}
+
+int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rng_user, R1CSProof *out) {
+    for (size_t j = 0; j < k; j++) {
+        int rc = ps[j]->prove_begin(rng_fn, rng_user);
+        if (rc) return rc;
+    }
+    for (size_t j0 = 0; j0 < k; j0 += 8) {
+        const size_t g = k - j0 < 8 ? k - j0 : 8;
+        const size_t n = ps[j0]->a_L_.size();
+        bool same = g > 1;
+        for (size_t l = 1; l < g; l++) same = same && ps[j0 + l]->a_L_.size() == n;
+        TranscriptRng *r[8];
+        for (size_t l = 0; l < 8; l++) r[l] = ps[j0 + (l < g ? l : 0)]->rng_.get();     // spare lanes repeat lane 0
+        TranscriptRngLanes8 lanes;
+        if (!same || !lanes.load(r)) {                      // different circuits: every prover on its own
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->draw_blindings();
+            continue;
+        }
+        const double t0 = now_ms();
+        sc d[8];
+        lanes.scalars(d);
+        for (size_t l = 0; l < g; l++) ps[j0 + l]->i_bl_ = d[l];
+        lanes.scalars(d);
+        for (size_t l = 0; l < g; l++) ps[j0 + l]->o_bl_ = d[l];
+        lanes.scalars(d);
+        for (size_t l = 0; l < g; l++) ps[j0 + l]->s_bl_ = d[l];
+        for (size_t l = 0; l < g; l++) {
+            ps[j0 + l]->s_L_.resize(n);
+            ps[j0 + l]->s_R_.resize(n);
+        }
+        for (size_t i = 0; i < n; i++) {
+            lanes.scalars(d);
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_L_[i] = d[l];
+        }
+        for (size_t i = 0; i < n; i++) {
+            lanes.scalars(d);
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_R_[i] = d[l];
+        }
+        lanes.store(r, (int)g);
+        const double per = (now_ms() - t0) / (double)g;
+        for (size_t l = 0; l < g; l++) ps[j0 + l]->timing.rng_ms = per;
+    }
+    for (size_t j = 0; j < k; j++) {
+        int rc = ps[j]->prove_finish(out[j]);
+        if (rc) return rc;
+    }
+    return BPG_OK;
+}
+
+int Prover::prove_finish(R1CSProof &P) {
     bpg_ctx *ctx = gens_->ctx;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
     const size_t n = a_L_.size(), m = v_.size();
     const size_t np = next_pow2(n ? n : 1);
-    if (gens_->capacity < np) return BPG_EGENS;
     size_t lg = 0;
     while (((size_t)1 << lg) < np) lg++;
-
-    // ---- transcript RNG (host, sequential Keccak)
-    tr_.append_u64("m", m);
-    TranscriptRng rng = tr_.build_rng();
-    for (size_t i = 0; i < m; i++) {
-        uint8_t b[32];
-        sc_tobytes(b, v_blinding_[i]);
-        rng.rekey_with_witness_bytes("v_blinding", b, 32);
-    }
-    uint8_t ext[32];
-    rng_fn(rng_user, ext, 32);
-    rng.finalize(ext);
-    const double t0 = now_ms();
-    sc i_bl = rng.scalar(), o_bl = rng.scalar(), s_bl = rng.scalar();
-    std::vector<sc> s_L(n), s_R(n);
-    for (size_t i = 0; i < n; i++) s_L[i] = rng.scalar();
-    for (size_t i = 0; i < n; i++) s_R[i] = rng.scalar();
-    timing.rng_ms = now_ms() - t0;
+    TranscriptRng &rng = *rng_;
+    const sc i_bl = i_bl_, o_bl = o_bl_, s_bl = s_bl_;
+    // the blinding vectors are only needed up to the upload below; the prover keeps nothing of them afterwards
+    std::vector<sc> s_L = std::move(s_L_), s_R = std::move(s_R_);
+    s_L_.clear();
+    s_R_.clear();
 
     // ---- device workspace
     FlatPlan fp;
@@ -1013,7 +1085,8 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     P.a = Scalar(ha);
     P.b = Scalar(hb);
     timing.ipp_ms = now_ms() - t3;
-    timing.total_ms = now_ms() - t_start;
+    timing.total_ms = now_ms() - t_start_;
+    rng_.reset();
     return BPG_OK;
 }
 

@@ -157,6 +157,27 @@ int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *pro
         return BPG_OK;
     });
 }
+int bpg_prover_prove_many(bpg_prover *const *provers, size_t k, bpg_rng_fn rng, void *rng_user, uint8_t *proofs_out, size_t cap_each,
+                          size_t *proof_lens) {
+    if (!rng || !proof_lens || (k && !provers)) return BPG_EINVAL;
+    for (size_t j = 0; j < k; j++)
+        if (!provers[j]) return BPG_EINVAL;
+    return guarded([&] {
+        std::vector<Prover *> ps(k);
+        for (size_t j = 0; j < k; j++) ps[j] = provers[j]->p;
+        std::vector<R1CSProof> proofs(k);
+        int rc = Prover::prove_many(ps.data(), k, rng, rng_user, proofs.data());
+        if (rc) return rc;
+        bool fits = proofs_out != nullptr;
+        for (size_t j = 0; j < k; j++) {
+            std::vector<uint8_t> b = proofs[j].to_bytes();
+            proof_lens[j] = b.size();
+            if (proofs_out && b.size() <= cap_each) memcpy(proofs_out + j * cap_each, b.data(), b.size());
+            else fits = false;
+        }
+        return fits ? BPG_OK : BPG_EINVAL;
+    });
+}
 int bpg_prover_stats(const bpg_prover *p, size_t *multipliers, size_t *constraints) {
     if (!p) return BPG_EINVAL;
     if (multipliers) *multipliers = p->p->num_multipliers();

@@ -214,6 +214,19 @@ class Prover(_CS):
         check(lib().bpg_prover_prove(self._h, cb, None, out, cap, ctypes.byref(n)))
         return Proof(out.raw[:n.value])
 
+    @staticmethod
+    def prove_many(provers, external_rng=b""):
+        """k proofs by this thread (bpg_prover_prove_many): the bytes of [p.prove() for p in provers] when the
+        same external randomness stream (32 bytes per proof, in order) is used"""
+        k = len(provers)
+        cb = _rng_cb(external_rng)
+        cap = 1 << 16
+        out = ctypes.create_string_buffer(cap * max(k, 1))
+        lens = (ctypes.c_size_t * max(k, 1))()
+        hs = (ctypes.c_void_p * max(k, 1))(*[p._h for p in provers])
+        check(lib().bpg_prover_prove_many(hs, k, cb, None, out, cap, lens))
+        return [Proof(out.raw[j * cap:j * cap + lens[j]]) for j in range(k)]
+
     def stats(self):
         a, b = ctypes.c_size_t(), ctypes.c_size_t()
         check(lib().bpg_prover_stats(self._h, ctypes.byref(a), ctypes.byref(b)))

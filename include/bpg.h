@@ -167,6 +167,14 @@ int bpg_prover_commit_batch(bpg_prover *p, const uint8_t *v32, const uint8_t *bl
 /* Prover::prove(&bp_gens) -> R1CSProof::to_bytes()   ref: tests/edwards_point.rs:47,134,215,320,391; scalar.rs:46; sk_know_gadget.rs:63
  * Returns BPG_EGENS for R1CSError::InvalidGeneratorsLength.  *proof_len is set even when cap is too small (BPG_EINVAL). */
 int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *proof_out, size_t cap, size_t *proof_len);
+/* k independent proofs by the calling thread: the same bytes as k bpg_prover_prove calls in this order with the
+ * same `rng` (which is asked for 32 bytes per proof, in order), i.e. the loop a caller of the reference writes
+ * around Prover::prove (ref: tests/edwards_point.rs:47,134,...: one prove per statement).  The blinding RNGs of up
+ * to eight provers of one circuit shape advance in lock-step (eight Keccak states per AVX-512 permutation), which
+ * takes most of the host time out of a proof.  Proof j is written at proofs_out + j * cap_each, its length to
+ * proof_lens[j].  BPG_EINVAL if a proof does not fit cap_each (proof_lens is still set). */
+int bpg_prover_prove_many(bpg_prover *const *provers, size_t k, bpg_rng_fn rng, void *rng_user, uint8_t *proofs_out, size_t cap_each,
+                          size_t *proof_lens);
 int bpg_prover_stats(const bpg_prover *p, size_t *multipliers, size_t *constraints);
 /* milliseconds of the last prove(): blinding RNG, A/S commitments, polynomial phase, inner-product argument, total */
 int bpg_prover_timing(const bpg_prover *p, double out_ms[5]);

@@ -83,4 +83,47 @@ void hh_transcript_rng(uint8_t *out, size_t n, const uint8_t *label, size_t labe
         sc_tobytes(out + 32 * i, s);
     }
 }
+// eight interleaved Keccak states st[25][8]; generic != 0 forces the per-lane scalar fallback
+void hh_keccak_x8(uint64_t *st, int generic) {
+    uint64_t (*s)[8] = (uint64_t (*)[8])st;
+    if (generic) {
+        for (int l = 0; l < 8; l++) {
+            uint64_t t[25];
+            for (int i = 0; i < 25; i++) t[i] = s[i][l];
+            keccak_f1600_generic(t);
+            for (int i = 0; i < 25; i++) s[i][l] = t[i];
+        }
+    } else {
+        keccak_f1600_x8(s);
+    }
+}
+// eight TranscriptRngs (witness / external randomness k of 8) drawn in lock-step: n scalars per lane through
+// TranscriptRngLanes8, then, after store(), `tail` more from each lane's own TranscriptRng.
+// out: lane-major, (n + tail) * 32 bytes per lane.  Returns 0 if the lanes could not be loaded.
+int hh_transcript_rng_lanes(uint8_t *out, size_t n, size_t tail, const uint8_t *label, size_t label_len, const uint8_t *witness32x8,
+                            const uint8_t *ext32x8) {
+    std::vector<TranscriptRng> rngs;
+    Transcript tr(label, label_len);
+    for (int l = 0; l < 8; l++) {
+        rngs.push_back(tr.build_rng());
+        rngs[l].rekey_with_witness_bytes("v_blinding", witness32x8 + 32 * l, 32);
+        rngs[l].finalize(ext32x8 + 32 * l);
+    }
+    TranscriptRng *ptr[8];
+    for (int l = 0; l < 8; l++) ptr[l] = &rngs[l];
+    TranscriptRngLanes8 lanes;
+    if (!lanes.load(ptr)) return 0;
+    for (size_t i = 0; i < n; i++) {
+        sc s[8];
+        lanes.scalars(s);
+        for (int l = 0; l < 8; l++) sc_tobytes(out + ((n + tail) * l + i) * 32, s[l]);
+    }
+    lanes.store(ptr, 8);
+    for (int l = 0; l < 8; l++)
+        for (size_t i = 0; i < tail; i++) {
+            sc s = rngs[l].scalar();
+            sc_tobytes(out + ((n + tail) * l + n + i) * 32, s);
+        }
+    return 1;
+}
 }

@@ -108,6 +108,39 @@ def test_host_transcript_rng_matches_oracle(host_hooks, oracle):
     assert out.raw == want
 
 
+def test_host_keccak_x8_and_rng_lanes(host_hooks, oracle):
+    """eight interleaved Keccak states (AVX-512 body where the CPU has it) against the one-state body, and eight
+    blinding RNGs drawn in lock-step against each RNG drawn on its own (the oracle's stream), including the
+    hand-back to the single-state RNG for the draws that follow"""
+    import ctypes
+    import random
+    from oracle import r1cs as R
+    rnd = random.Random(8)
+    for _ in range(10):
+        st = [rnd.getrandbits(64) for _ in range(200)]
+        a = (ctypes.c_uint64 * 200)(*st)
+        b = (ctypes.c_uint64 * 200)(*st)
+        host_hooks.hh_keccak_x8(a, 0)
+        host_hooks.hh_keccak_x8(b, 1)
+        assert list(a) == list(b)
+        one = (ctypes.c_uint64 * 25)(*[st[8 * i + 3] for i in range(25)])
+        host_hooks.hh_keccak_f(one, 0)
+        assert list(one) == [a[8 * i + 3] for i in range(25)]
+    n, tail = 40, 5
+    wits = [bytes(rnd.randrange(256) for _ in range(31)) + b"\x03" for _ in range(8)]
+    exts = [bytes(rnd.randrange(256) for _ in range(32)) for _ in range(8)]
+    out = ctypes.create_string_buffer(32 * (n + tail) * 8)
+    host_hooks.hh_transcript_rng_lanes.restype = ctypes.c_int
+    ok = host_hooks.hh_transcript_rng_lanes(out, ctypes.c_size_t(n), ctypes.c_size_t(tail), b"lanes-test", ctypes.c_size_t(10),
+                                            b"".join(wits), b"".join(exts))
+    assert ok == 1
+    for lane in range(8):
+        tr = R.Transcript(oracle, b"lanes-test")
+        rng = tr.build_rng([int.from_bytes(wits[lane], "little")], exts[lane])
+        want = b"".join(x.to_bytes(32, "little") for x in rng.scalars(n + tail))
+        assert out.raw[32 * (n + tail) * lane:32 * (n + tail) * (lane + 1)] == want, lane
+
+
 def test_termvec_under_sanitizers(tmp_path):
     """LinearCombination's inline small-vector (r1cs.h: TermVec), host code, built with ASan + UBSan"""
     import os

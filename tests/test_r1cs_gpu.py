@@ -300,3 +300,40 @@ def test_verify_batch(gbe, obe, rnd):
     bad[1] = g.Proof(bytes(raw))
     with pytest.raises(g.VerificationError):
         g.verify_batch(verifiers(), bad, bp, ext)
+
+
+def test_prove_many_equals_sequential_proves(gbe, rnd):
+    """bpg_prover_prove_many: k proofs by one thread with their blinding RNGs drawn in lock-step (eight Keccak
+    states per permutation).  Bytes must equal those of k separate prove() calls fed the same external randomness,
+    which the tests above pin against the oracle: groups of fewer than, exactly and more than eight provers of
+    one circuit (different witnesses), provers with committed variables (the RNG is rekeyed with their blindings),
+    and mixed circuit shapes (those fall back to one RNG at a time)."""
+    import hashlib
+    from bulletproofs_gadgets_amd import r1cs as g
+    bp = gbe.bp_gens(256)
+
+    def build(kind, a, b, seed):
+        if kind == "radd":
+            p = gbe.Prover(b"RistrettoAdd")
+            ra, rb = sonny.RistrettoPoint(a), sonny.RistrettoPoint(b)
+            _radd_circuit(gbe, p, ra, rb, ra + rb)
+        elif kind == "eadd":
+            p = gbe.Prover(b"Point Addition")
+            _eadd_circuit(gbe, p, a, b, a + b)
+        else:
+            p = gbe.Prover(b"PointDouble")
+            srng = R.SeededRng(seed)
+            g1, _ = gbe.EdwardsGadget.prover_commit_to_sonny_edwards_point(p, a, srng)
+            g2, _ = gbe.EdwardsGadget.prover_commit_to_sonny_edwards_point(p, a, srng)
+            g1.equal(g2, p)
+        return p
+
+    for kinds in (["radd"], ["radd"] * 3, ["eadd"] * 8, ["radd"] * 11, ["commit"] * 5, ["radd", "eadd", "commit", "radd", "eadd"],
+                  ["eadd"] * 8 + ["radd"] * 2):
+        k = len(kinds)
+        wit = [(sonny.random_point(rnd), sonny.random_point(rnd)) for _ in range(k)]
+        ext = b"".join(hashlib.sha256(b"pm%d-%d" % (k, j)).digest() for j in range(k))
+        one_by_one = [build(kinds[j], *wit[j], b"s%d" % j).prove(bp, ext[32 * j:32 * j + 32]).to_bytes() for j in range(k)]
+        many = g.Prover.prove_many([build(kinds[j], *wit[j], b"s%d" % j) for j in range(k)], ext)
+        assert [p.to_bytes() for p in many] == one_by_one, kinds
+    assert g.Prover.prove_many([]) == []
