@@ -271,6 +271,7 @@ class Prover : public ConstraintSystem {
     int prove_begin(rng_fill_fn rng, void *rng_user);
     void draw_blindings();
     int prove_finish(R1CSProof &out);
+    static int finish_group(Prover *const *ps, size_t g, R1CSProof *out);
     Gens *gens_;
     Transcript tr_;
     ConstraintStore cs_;

@@ -919,174 +919,267 @@ int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rn
         const double per = (now_ms() - t0) / (double)g;
         for (size_t l = 0; l < g; l++) ps[j0 + l]->timing.rng_ms = per;
     }
-    for (size_t j = 0; j < k; j++) {
-        int rc = ps[j]->prove_finish(out[j]);
+    // the GPU part: consecutive provers of one size and generator object share their MSM launches
+    const size_t gmax = 8;
+    for (size_t j0 = 0; j0 < k;) {
+        size_t g = 1;
+        while (j0 + g < k && g < gmax && ps[j0 + g]->a_L_.size() == ps[j0]->a_L_.size() && ps[j0 + g]->gens_ == ps[j0]->gens_) g++;
+        int rc = finish_group(ps + j0, g, out + j0);
         if (rc) return rc;
+        j0 += g;
     }
     return BPG_OK;
 }
 
 int Prover::prove_finish(R1CSProof &P) {
-    bpg_ctx *ctx = gens_->ctx;
+    Prover *self = this;
+    return finish_group(&self, 1, &P);
+}
+
+// Everything after the blinding draws, for g provers of the same size at once on the calling thread's lane.
+// Each proof keeps its own transcript, challenges and vectors; what is shared is the launch of every
+// multiscalar multiplication: one 3g-target MSM for the A_I / A_O / S commitments and one 2g-target MSM per
+// inner-product round, so the latency-bound kernels around the accumulate pass run once per round, not once
+// per round and proof.  g = 1 is the single proof.
+int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
+    struct PF {
+        FlatPlan fp;
+        sc *d_rows, *d_aL, *d_aR, *d_aO, *d_sL, *d_sR;
+        sc *d_W, *d_ytbl, *d_yinvtbl, *d_l1, *d_r0, *d_r1, *d_r3, *d_part;
+        sc *d_a, *d_b, *d_sG, *d_sH, *d_rowLR, *d_cpart;
+        std::vector<sc> h_part, wV;
+        Scalar y, z, u, x, w, t[7], tb[7];
+        sc ytbl[32], yinvtbl[32];                           // sources of async copies: alive until the next sync
+    };
+    Gens *gens = ps[0]->gens_;
+    bpg_ctx *ctx = gens->ctx;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
-    const size_t n = a_L_.size(), m = v_.size();
+    const size_t n = ps[0]->a_L_.size();
+    for (size_t j = 1; j < g; j++)
+        if (ps[j]->a_L_.size() != n || ps[j]->gens_ != gens) return BPG_EINVAL;
     const size_t np = next_pow2(n ? n : 1);
     size_t lg = 0;
     while (((size_t)1 << lg) < np) lg++;
-    TranscriptRng &rng = *rng_;
-    const sc i_bl = i_bl_, o_bl = o_bl_, s_bl = s_bl_;
-    // the blinding vectors are only needed up to the upload below; the prover keeps nothing of them afterwards
-    std::vector<sc> s_L = std::move(s_L_), s_R = std::move(s_R_);
-    s_L_.clear();
-    s_R_.clear();
+    std::vector<PF> pf(g);
 
     // ---- device workspace
-    FlatPlan fp;
-    build_flat_plan(cs_, (uint32_t)n, (uint32_t)m, false, fp);
     const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
     const size_t nblk_n = grid256(n ? n : 1), nblk_np = grid256(np);
-    size_t need = pad256(3 * N1 * 32) + 5 * pad256((n + 1) * 32) + pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) +
-                  4 * pad256((n + 1) * 32) + pad256(nblk_n * 6 * 32) + 2 * pad256(32 * 32) + 4 * pad256(np * 32) +
-                  pad256(2 * NR * 32) + pad256(nblk_np * 2 * 32) + (1 << 16);
+    size_t need = pad256(g * 3 * N1 * 32) + pad256(g * 2 * NR * 32) + (1 << 16);
+    for (size_t j = 0; j < g; j++) {
+        Prover &p = *ps[j];
+        build_flat_plan(p.cs_, (uint32_t)n, (uint32_t)p.v_.size(), false, pf[j].fp);
+        need += 5 * pad256((n + 1) * 32) + pad256((pf[j].fp.nslots + 1) * 32) + flatten_bytes(p.cs_, pf[j].fp) +
+                4 * pad256((n + 1) * 32) + pad256(nblk_n * 6 * 32) + 2 * pad256(32 * 32) + 4 * pad256(np * 32) +
+                pad256(nblk_np * 2 * 32) + (1 << 12);
+    }
     Arena ar(lane);
     int rc = ar.reserve(need);
     if (rc) return rc;
-    sc *d_rows = ar.take<sc>(3 * N1);
-    sc *d_aL = d_rows + 1, *d_aR = d_rows + 1 + n;             // row 0 = [i_bl | a_L | a_R]
-    sc *d_aO = d_rows + N1 + 1;                                 // row 1 = [o_bl | a_O | 0]
-    sc *d_sL = d_rows + 2 * N1 + 1, *d_sR = d_rows + 2 * N1 + 1 + n;   // row 2 = [s_bl | s_L | s_R]
-    BPG_CHECK_HIP(hipMemsetAsync(d_rows, 0, 3 * N1 * 32, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_rows, &i_bl, 32, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_rows + N1, &o_bl, 32, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_rows + 2 * N1, &s_bl, 32, hipMemcpyHostToDevice, s));
-    if (n) {
-        BPG_CHECK_HIP(hipMemcpyAsync(d_aL, a_L_.data(), n * 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_aR, a_R_.data(), n * 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_aO, a_O_.data(), n * 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_sL, s_L.data(), n * 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_sR, s_R.data(), n * 32, hipMemcpyHostToDevice, s));
+    sc *d_rows_all = ar.take<sc>(g * 3 * N1);             // proof j: rows 3j .. 3j+2
+    sc *d_rowLR_all = ar.take<sc>(g * 2 * NR);            // proof j: rows 2j, 2j+1
+    BPG_CHECK_HIP(hipMemsetAsync(d_rows_all, 0, g * 3 * N1 * 32, s));
+    std::vector<std::vector<sc>> keep_sL(g), keep_sR(g);  // pageable sources of async copies: alive until the sync
+    for (size_t j = 0; j < g; j++) {
+        Prover &p = *ps[j];
+        PF &f = pf[j];
+        // the blinding vectors are only needed up to the upload; the prover keeps nothing of them afterwards
+        keep_sL[j] = std::move(p.s_L_);
+        keep_sR[j] = std::move(p.s_R_);
+        p.s_L_.clear();
+        p.s_R_.clear();
+        f.d_rows = d_rows_all + j * 3 * N1;
+        f.d_aL = f.d_rows + 1;                              // row 0 = [i_bl | a_L | a_R]
+        f.d_aR = f.d_rows + 1 + n;
+        f.d_aO = f.d_rows + N1 + 1;                         // row 1 = [o_bl | a_O | 0]
+        f.d_sL = f.d_rows + 2 * N1 + 1;                     // row 2 = [s_bl | s_L | s_R]
+        f.d_sR = f.d_rows + 2 * N1 + 1 + n;
+        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows, &p.i_bl_, 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + N1, &p.o_bl_, 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + 2 * N1, &p.s_bl_, 32, hipMemcpyHostToDevice, s));
+        if (n) {
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, p.a_L_.data(), n * 32, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, p.a_R_.data(), n * 32, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, p.a_O_.data(), n * 32, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_sL, keep_sL[j].data(), n * 32, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_sR, keep_sR[j].data(), n * 32, hipMemcpyHostToDevice, s));
+        }
     }
     BPG_CHECK_HIP(hipStreamSynchronize(s));
+    keep_sL.clear();
+    keep_sR.clear();
 
-    // ---- A_I1, A_O1, S1: one 3-target MSM over [B~ | G[0..n) | H[0..n)]
+    // ---- A_I1, A_O1, S1 of every proof: one 3g-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
     {
-        msm_seg segs[3] = {pedersen_seg(gens_, 1, 1, 0), gen_seg(gens_, 0, 0, n, 1), gen_seg(gens_, 1, 0, n, 1 + n)};
-        uint8_t out[96];
-        if ((rc = gens_msm(gens_, segs, 3, d_rows, N1, 3, out))) return rc;
-        memcpy(P.A_I1, out, 32);
-        memcpy(P.A_O1, out + 32, 32);
-        memcpy(P.S1, out + 64, 32);
+        msm_seg segs[3] = {pedersen_seg(gens, 1, 1, 0), gen_seg(gens, 0, 0, n, 1), gen_seg(gens, 1, 0, n, 1 + n)};
+        std::vector<uint8_t> o(96 * g);
+        if ((rc = gens_msm(gens, segs, 3, d_rows_all, N1, (int)(3 * g), o.data()))) return rc;
+        for (size_t j = 0; j < g; j++) {
+            memcpy(out[j].A_I1, &o[96 * j], 32);
+            memcpy(out[j].A_O1, &o[96 * j + 32], 32);
+            memcpy(out[j].S1, &o[96 * j + 64], 32);
+        }
     }
-    timing.commit_ms = now_ms() - t1;
-    tr_.append_point("A_I1", P.A_I1);
-    tr_.append_point("A_O1", P.A_O1);
-    tr_.append_point("S1", P.S1);
-    tr_.r1cs_1phase_domain_sep();          // the reference's gadgets register no randomized constraints
-    memset(P.A_I2, 0, 32);
-    memset(P.A_O2, 0, 32);
-    memset(P.S2, 0, 32);
-    tr_.append_point("A_I2", P.A_I2);
-    tr_.append_point("A_O2", P.A_O2);
-    tr_.append_point("S2", P.S2);
-    const Scalar y = tr_.challenge_scalar("y"), z = tr_.challenge_scalar("z");
+    const double commit_ms = (now_ms() - t1) / (double)g;
 
-    // ---- flatten, l/r polynomials, t coefficients
+    // ---- challenges y, z; flatten, l/r polynomials, t coefficients
     const double t2 = now_ms();
-    sc *d_W = ar.take<sc>(fp.nslots + 1);
-    if ((rc = gpu_flatten(lane, ar, cs_, fp, z.v, d_W))) return rc;
-    sc ytbl[32], yinvtbl[32];
-    const Scalar y_inv = y.invert();
-    pow2_table(ytbl, y.v);
-    pow2_table(yinvtbl, y_inv.v);
-    sc *d_ytbl = ar.take<sc>(32), *d_yinvtbl = ar.take<sc>(32);
-    BPG_CHECK_HIP(hipMemcpyAsync(d_ytbl, ytbl, sizeof ytbl, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_yinvtbl, yinvtbl, sizeof yinvtbl, hipMemcpyHostToDevice, s));
-    sc *d_l1 = ar.take<sc>(n + 1), *d_r0 = ar.take<sc>(n + 1), *d_r1 = ar.take<sc>(n + 1), *d_r3 = ar.take<sc>(n + 1);
-    sc *d_part = ar.take<sc>(nblk_n * 6);
-    std::vector<sc> h_part(nblk_n * 6), wV(m);
-    Scalar t[7];
-    if (n) {
-        hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n), dim3(256), 0, s, (uint32_t)n, d_aL, d_aR, d_aO, d_sL, d_sR, d_W, d_ytbl,
-                           d_yinvtbl, d_l1, d_r0, d_r1, d_r3, d_part);
-        BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
+    for (size_t j = 0; j < g; j++) {
+        Prover &p = *ps[j];
+        PF &f = pf[j];
+        R1CSProof &P = out[j];
+        const size_t m = p.v_.size();
+        p.timing.commit_ms = commit_ms;
+        p.tr_.append_point("A_I1", P.A_I1);
+        p.tr_.append_point("A_O1", P.A_O1);
+        p.tr_.append_point("S1", P.S1);
+        p.tr_.r1cs_1phase_domain_sep();          // the reference's gadgets register no randomized constraints
+        memset(P.A_I2, 0, 32);
+        memset(P.A_O2, 0, 32);
+        memset(P.S2, 0, 32);
+        p.tr_.append_point("A_I2", P.A_I2);
+        p.tr_.append_point("A_O2", P.A_O2);
+        p.tr_.append_point("S2", P.S2);
+        f.y = p.tr_.challenge_scalar("y");
+        f.z = p.tr_.challenge_scalar("z");
+        f.d_W = ar.take<sc>(f.fp.nslots + 1);
+        if ((rc = gpu_flatten(lane, ar, p.cs_, f.fp, f.z.v, f.d_W))) return rc;
+        const Scalar y_inv = f.y.invert();
+        pow2_table(f.ytbl, f.y.v);
+        pow2_table(f.yinvtbl, y_inv.v);
+        f.d_ytbl = ar.take<sc>(32);
+        f.d_yinvtbl = ar.take<sc>(32);
+        BPG_CHECK_HIP(hipMemcpyAsync(f.d_ytbl, f.ytbl, sizeof f.ytbl, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(f.d_yinvtbl, f.yinvtbl, sizeof f.yinvtbl, hipMemcpyHostToDevice, s));
+        f.d_l1 = ar.take<sc>(n + 1);
+        f.d_r0 = ar.take<sc>(n + 1);
+        f.d_r1 = ar.take<sc>(n + 1);
+        f.d_r3 = ar.take<sc>(n + 1);
+        f.d_part = ar.take<sc>(nblk_n * 6);
+        f.h_part.resize(nblk_n * 6);
+        f.wV.resize(m);
+        if (n) {
+            hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n), dim3(256), 0, s, (uint32_t)n, f.d_aL, f.d_aR, f.d_aO, f.d_sL, f.d_sR, f.d_W,
+                               f.d_ytbl, f.d_yinvtbl, f.d_l1, f.d_r0, f.d_r1, f.d_r3, f.d_part);
+            BPG_CHECK_HIP(hipGetLastError());
+            BPG_CHECK_HIP(hipMemcpyAsync(f.h_part.data(), f.d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
+        }
+        if (m) BPG_CHECK_HIP(hipMemcpyAsync(f.wV.data(), f.d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
     }
-    if (m) BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    if (n)
-        for (size_t b = 0; b < nblk_n; b++)
-            for (int k = 0; k < 6; k++) t[k + 1] += Scalar(h_part[b * 6 + k]);
 
-    // ---- T_1, T_3..T_6
-    Scalar tb[7];
-    tb[1] = rng.scalar(); tb[3] = rng.scalar(); tb[4] = rng.scalar(); tb[5] = rng.scalar(); tb[6] = rng.scalar();
+    // ---- T_1, T_3..T_6 of every proof: one batch of 5g Pedersen commitments
     {
-        sc vr[10] = {t[1].v, tb[1].v, t[3].v, tb[3].v, t[4].v, tb[4].v, t[5].v, tb[5].v, t[6].v, tb[6].v};
-        uint8_t Ts[160];
-        if ((rc = pedersen_batch(gens_, vr, 5, Ts))) return rc;
-        memcpy(P.T_1, Ts, 32); memcpy(P.T_3, Ts + 32, 32); memcpy(P.T_4, Ts + 64, 32);
-        memcpy(P.T_5, Ts + 96, 32); memcpy(P.T_6, Ts + 128, 32);
+        std::vector<sc> vr(10 * g);
+        std::vector<uint8_t> Ts(160 * g);
+        for (size_t j = 0; j < g; j++) {
+            PF &f = pf[j];
+            TranscriptRng &rng = *ps[j]->rng_;
+            if (n)
+                for (size_t b = 0; b < nblk_n; b++)
+                    for (int k = 0; k < 6; k++) f.t[k + 1] += Scalar(f.h_part[b * 6 + k]);
+            f.tb[1] = rng.scalar(); f.tb[3] = rng.scalar(); f.tb[4] = rng.scalar(); f.tb[5] = rng.scalar(); f.tb[6] = rng.scalar();
+            const sc row[10] = {f.t[1].v, f.tb[1].v, f.t[3].v, f.tb[3].v, f.t[4].v, f.tb[4].v, f.t[5].v, f.tb[5].v, f.t[6].v, f.tb[6].v};
+            memcpy(&vr[10 * j], row, sizeof row);
+        }
+        if ((rc = pedersen_batch(gens, vr.data(), 5 * g, Ts.data()))) return rc;
+        for (size_t j = 0; j < g; j++) {
+            R1CSProof &P = out[j];
+            const uint8_t *T5 = &Ts[160 * j];
+            memcpy(P.T_1, T5, 32); memcpy(P.T_3, T5 + 32, 32); memcpy(P.T_4, T5 + 64, 32);
+            memcpy(P.T_5, T5 + 96, 32); memcpy(P.T_6, T5 + 128, 32);
+        }
     }
-    tr_.append_point("T_1", P.T_1);
-    tr_.append_point("T_3", P.T_3);
-    tr_.append_point("T_4", P.T_4);
-    tr_.append_point("T_5", P.T_5);
-    tr_.append_point("T_6", P.T_6);
-    const Scalar u = tr_.challenge_scalar("u"), x = tr_.challenge_scalar("x");
-    for (size_t j = 0; j < m; j++) tb[2] += Scalar(wV[j]) * Scalar(v_blinding_[j]);
-    P.t_x = x * (t[1] + x * (t[2] + x * (t[3] + x * (t[4] + x * (t[5] + x * t[6])))));
-    P.t_x_blinding = x * (tb[1] + x * (tb[2] + x * (tb[3] + x * (tb[4] + x * (tb[5] + x * tb[6])))));
-    P.e_blinding = x * (Scalar(i_bl) + x * (Scalar(o_bl) + x * Scalar(s_bl)));   // second-phase blindings are zero
-    tr_.append_scalar("t_x", P.t_x.v);
-    tr_.append_scalar("t_x_blinding", P.t_x_blinding.v);
-    tr_.append_scalar("e_blinding", P.e_blinding.v);
-    const Scalar w = tr_.challenge_scalar("w");
 
-    // ---- l(x), r(x) -> IPP vectors
-    sc *d_a = ar.take<sc>(np), *d_b = ar.take<sc>(np), *d_sG = ar.take<sc>(np), *d_sH = ar.take<sc>(np);
-    hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, x.v, u.v, d_l1, d_aO, d_sL,
-                       d_r0, d_r1, d_r3, d_ytbl, d_yinvtbl, d_a, d_b, d_sG, d_sH);
-    BPG_CHECK_HIP(hipGetLastError());
-    timing.poly_ms = now_ms() - t2;
+    // ---- challenges u, x, w; l(x), r(x) -> IPP vectors
+    for (size_t j = 0; j < g; j++) {
+        Prover &p = *ps[j];
+        PF &f = pf[j];
+        R1CSProof &P = out[j];
+        const size_t m = p.v_.size();
+        p.tr_.append_point("T_1", P.T_1);
+        p.tr_.append_point("T_3", P.T_3);
+        p.tr_.append_point("T_4", P.T_4);
+        p.tr_.append_point("T_5", P.T_5);
+        p.tr_.append_point("T_6", P.T_6);
+        f.u = p.tr_.challenge_scalar("u");
+        f.x = p.tr_.challenge_scalar("x");
+        const Scalar &x = f.x;
+        const Scalar *t = f.t;
+        Scalar *tb = f.tb;
+        for (size_t i = 0; i < m; i++) tb[2] += Scalar(f.wV[i]) * Scalar(p.v_blinding_[i]);
+        P.t_x = x * (t[1] + x * (t[2] + x * (t[3] + x * (t[4] + x * (t[5] + x * t[6])))));
+        P.t_x_blinding = x * (tb[1] + x * (tb[2] + x * (tb[3] + x * (tb[4] + x * (tb[5] + x * tb[6])))));
+        P.e_blinding = x * (Scalar(p.i_bl_) + x * (Scalar(p.o_bl_) + x * Scalar(p.s_bl_)));   // second-phase blindings are zero
+        p.tr_.append_scalar("t_x", P.t_x.v);
+        p.tr_.append_scalar("t_x_blinding", P.t_x_blinding.v);
+        p.tr_.append_scalar("e_blinding", P.e_blinding.v);
+        f.w = p.tr_.challenge_scalar("w");
+        f.d_a = ar.take<sc>(np);
+        f.d_b = ar.take<sc>(np);
+        f.d_sG = ar.take<sc>(np);
+        f.d_sH = ar.take<sc>(np);
+        f.d_cpart = ar.take<sc>(nblk_np * 2);
+        f.d_rowLR = d_rowLR_all + j * 2 * NR;
+        hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, f.x.v, f.u.v, f.d_l1, f.d_aO,
+                           f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH);
+        BPG_CHECK_HIP(hipGetLastError());
+        p.tr_.innerproduct_domain_sep(np);
+        P.L_vec.assign(32 * lg, 0);
+        P.R_vec.assign(32 * lg, 0);
+    }
+    const double poly_ms = (now_ms() - t2) / (double)g;
 
-    // ---- inner-product argument, fold-free
+    // ---- inner-product argument, fold-free: one 2g-target MSM per round
     const double t3 = now_ms();
-    tr_.innerproduct_domain_sep(np);
-    sc *d_rowLR = ar.take<sc>(2 * NR), *d_cpart = ar.take<sc>(nblk_np * 2);
-    P.L_vec.assign(32 * lg, 0);
-    P.R_vec.assign(32 * lg, 0);
     size_t nk = np;
+    std::vector<uint8_t> lr(64 * g);
     for (size_t k = 0; k < lg; k++, nk >>= 1) {
-        hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, d_a, d_b, d_sG, d_sH,
-                           d_rowLR, d_rowLR + NR, d_cpart);
-        hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, d_cpart, (uint32_t)nblk_np, w.v, d_rowLR + 2 * np,
-                           d_rowLR + NR + 2 * np);
+        for (size_t j = 0; j < g; j++) {
+            PF &f = pf[j];
+            hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, f.d_a, f.d_b, f.d_sG,
+                               f.d_sH, f.d_rowLR, f.d_rowLR + NR, f.d_cpart);
+            hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, f.d_cpart, (uint32_t)nblk_np, f.w.v, f.d_rowLR + 2 * np,
+                               f.d_rowLR + NR + 2 * np);
+        }
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(hipStreamSynchronize(s));
-        msm_seg segs[3] = {gen_seg(gens_, 0, 0, np, 0), gen_seg(gens_, 1, 0, np, np), pedersen_seg(gens_, 0, 1, 2 * np)};
-        uint8_t out[64];
-        if ((rc = gens_msm(gens_, segs, 3, d_rowLR, NR, 2, out, 0.5f))) return rc;     // half of every row is zero
-        memcpy(&P.L_vec[32 * k], out, 32);
-        memcpy(&P.R_vec[32 * k], out + 32, 32);
-        tr_.append_point("L", out);
-        tr_.append_point("R", out + 32);
-        const Scalar uk = tr_.challenge_scalar("u"), uk_inv = uk.invert();
-        hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, uk.v, uk_inv.v, d_a,
-                           d_b, d_sG, d_sH);
+        msm_seg segs[3] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np), pedersen_seg(gens, 0, 1, 2 * np)};
+        if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f))) return rc;     // half of every row is zero
+        for (size_t j = 0; j < g; j++) {
+            Prover &p = *ps[j];
+            PF &f = pf[j];
+            R1CSProof &P = out[j];
+            const uint8_t *o = &lr[64 * j];
+            memcpy(&P.L_vec[32 * k], o, 32);
+            memcpy(&P.R_vec[32 * k], o + 32, 32);
+            p.tr_.append_point("L", o);
+            p.tr_.append_point("R", o + 32);
+            const Scalar uk = p.tr_.challenge_scalar("u"), uk_inv = uk.invert();
+            hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, uk.v, uk_inv.v, f.d_a,
+                               f.d_b, f.d_sG, f.d_sH);
+        }
         BPG_CHECK_HIP(hipGetLastError());
     }
-    sc ha, hb;
-    BPG_CHECK_HIP(hipMemcpyAsync(&ha, d_a, 32, hipMemcpyDeviceToHost, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(&hb, d_b, 32, hipMemcpyDeviceToHost, s));
+    std::vector<sc> hab(2 * g);
+    for (size_t j = 0; j < g; j++) {
+        BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j], pf[j].d_a, 32, hipMemcpyDeviceToHost, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j + 1], pf[j].d_b, 32, hipMemcpyDeviceToHost, s));
+    }
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    P.a = Scalar(ha);
-    P.b = Scalar(hb);
-    timing.ipp_ms = now_ms() - t3;
-    timing.total_ms = now_ms() - t_start_;
-    rng_.reset();
+    const double ipp_ms = (now_ms() - t3) / (double)g, t_end = now_ms();
+    for (size_t j = 0; j < g; j++) {
+        Prover &p = *ps[j];
+        out[j].a = Scalar(hab[2 * j]);
+        out[j].b = Scalar(hab[2 * j + 1]);
+        p.timing.poly_ms = poly_ms;
+        p.timing.ipp_ms = ipp_ms;
+        p.timing.total_ms = t_end - p.t_start_;
+        p.rng_.reset();
+    }
     return BPG_OK;
 }
 
