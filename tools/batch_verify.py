@@ -44,10 +44,16 @@ def run(ctx, gens, k, threads, rank=0):
 
     def prove_range(lo, hi):
         try:
-            for i in range(lo, hi):
-                p = g.Prover(gens, b"RistrettoAdd")
-                circuit(p, sts[i])
-                proofs[i] = p.prove(gens, hashlib.sha256(b"bv%d/%d" % (rank, i)).digest())
+            for i0 in range(lo, hi, 8):             # eight statements per bpg_prover_prove_many call
+                idx = range(i0, min(hi, i0 + 8))
+                ps = []
+                for i in idx:
+                    p = g.Prover(gens, b"RistrettoAdd")
+                    circuit(p, sts[i])
+                    ps.append(p)
+                ext = b"".join(hashlib.sha256(b"bv%d/%d" % (rank, i)).digest() for i in idx)
+                for i, proof in zip(idx, g.Prover.prove_many(ps, ext)):
+                    proofs[i] = proof
         except Exception as e:      # noqa: BLE001
             errs.append(repr(e))
     prove_range(0, 1)
