@@ -10,13 +10,15 @@
 // Pipeline for n scalars x T targets, window c bits, W = 255/c+1 windows,
 // NB = 2^(c-1) signed buckets per window:
 //   k_digits      scalar -> W signed digits (int16), [target][window][i] layout   (HBM stream)
-//   k_bin_hist / k_bin_scan / k_bin_scatter / k_bin_sort
+//   k_bin_hist / k_bin_scan / k_bin_scatter / k_chunk_count / k_chunk_offsets / k_chunk_place
 //                 two-level bucket sort of the entries (point index | sign): bins, then buckets
-//                 inside a bin with LDS cursors; yields bucket counts and entry offsets
+//                 inside a bin with LDS cursors, a bin in chunks of bounded size so that skewed
+//                 digits cannot pile a window onto one block; yields bucket counts and entry offsets
 //   k_scan_a/b    exclusive scans: thread offsets of every pass
 //   k_segmap      thread -> bucket maps of the accumulate pass and the first merge pass
-//   k_accumulate  P threads per bucket: mixed additions (7M each)                  (VALU int32: the hot kernel)
-//   k_tail_a/b    merge the P partials, then an LDS binary tree that yields, per
+//   k_accumulate  ceil(cnt / S0) threads per bucket: mixed additions (7M each)     (VALU int32: the hot kernel)
+//   k_reduce      merge passes: S1 partials per thread until one sum per bucket is left
+//   k_tail_a/b    an LDS binary tree that yields, per
 //                 window, the bucket total and the c-1 "bit j of bucket index"
 //                 sums in depth c-1 (sum_b (b+1) B_b = total + sum_j 2^j S_j)
 //   host          Horner over the W*c bit positions (one 255-doubling chain, which a
