@@ -147,8 +147,8 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
 
         def worker(tid, warm):
             try:
-                if warm:
-                    one(b"%d/%d/w" % (rank, tid), verify)
+                if warm:                               # same call shape as the timed pass: the lane's buffers reach their final size
+                    many([b"%d/%d/w%d" % (rank, tid, r) for r in range(per_call)], verify)
                 for r0 in range(0, 0 if warm else per_thread, per_call):
                     many([b"%d/%d/%d" % (rank, tid, r) for r in range(r0, min(per_thread, r0 + per_call))], verify)
             except Exception as e:  # noqa: BLE001

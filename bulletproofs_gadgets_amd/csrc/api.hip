@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points (include/bpg.h): context, device memory helpers,
 // resident point tables (batch ristretto decode / Elligator / compress kernels),
 // and the MSM entry points.  No CPU fallback: bpg_init fails without a GPU.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,15 +97,46 @@ __global__ void __launch_bounds__(256) k_compress(const aniels_rec *__restrict__
 
 static std::atomic<uint64_t> g_next_ctx_id{1};
 
+// live contexts by id: a thread that exits hands its lanes back to the contexts that still exist
+static std::mutex g_live_mu;
+static std::vector<bpg_ctx *> g_live;
+
+namespace {
+struct LaneSlot {
+    uint64_t id;
+    bpg_lane *lane;
+};
+// A lane holds a thread's streams and workspaces (gigabytes for grouped proofs): threads come and go (a pool that
+// is rebuilt, one thread per request), so a lane outlives its thread and is taken over by the next new one.
+struct LaneCache {
+    std::vector<LaneSlot> slots;
+    ~LaneCache() {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (auto &s : slots)
+            for (bpg_ctx *c : g_live)
+                if (c->id == s.id) {
+                    std::lock_guard<std::mutex> lk2(c->mu);
+                    c->free_lanes.push_back(s.lane);
+                }
+    }
+};
+}  // namespace
+
 bpg_lane *lane_of(bpg_ctx *ctx) {
-    struct Slot {
-        uint64_t id;
-        bpg_lane *lane;
-    };
-    static thread_local std::vector<Slot> cache;
+    static thread_local LaneCache tl;
+    auto &cache = tl.slots;
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     for (auto &s : cache)
         if (s.id == ctx->id) return s.lane;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->free_lanes.empty()) {
+            bpg_lane *lane = ctx->free_lanes.back();
+            ctx->free_lanes.pop_back();
+            cache.push_back({ctx->id, lane});
+            return lane;
+        }
+    }
     bpg_lane *lane = new bpg_lane();
     lane->ctx = ctx;
     hipError_t e = hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
@@ -272,6 +304,11 @@ int bpg_init(int device_id, bpg_ctx **out) {
     if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS1")) ctx->tune.ls1 = atoi(s);
     if (const char *s = getenv("BPG_MSM_SORT_CHUNK")) ctx->tune.sort_chunk = atoi(s);
+    if (const char *s = getenv("BPG_IPP_FOLD")) ctx->tune.ipp_fold = atoi(s);
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(ctx);
+    }
     *out = ctx;
     return BPG_OK;
 }
@@ -280,6 +317,10 @@ void bpg_shutdown(bpg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     // no call may be in flight on any thread; lanes of threads that have exited are freed here too
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+    }
     for (auto *lane : ctx->lanes) {
         for (auto *j : lane->jobs) msm_job_destroy(j);
         (void)hipStreamSynchronize(lane->stream);

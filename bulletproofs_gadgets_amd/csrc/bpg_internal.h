@@ -60,6 +60,8 @@ struct msm_plan {
 struct msm_tuning {
     int c = 0, tile = 0, ls0 = 0, ls1 = 0;   // 0 = automatic (BPG_MSM_C / _TILE / _LS0 / _LS1 env overrides)
     int sort_chunk = 0;                      // 0 = automatic (BPG_MSM_SORT_CHUNK)
+    int ipp_fold = -1;                       // inner-product round after which the folded generators are materialized
+                                             // (BPG_IPP_FOLD; 0 = never, -1 = default)
 };
 msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c = 0, float density = 1.f, int resident_lanes = 262144);
 // fixed-base (precomputed 2^(c w) multiples) geometry for a table of `points` generators
@@ -128,8 +130,9 @@ struct bpg_ctx {
     uint64_t id = 0;                  // process-unique; keys the per-thread lane cache
     bpg::msm_tuning tune;
     int resident_lanes = 262144;      // CUs x 4 SIMDs x 4 waves x 64 lanes: threads of k_accumulate resident at once
-    std::mutex mu;                    // guards lanes
+    std::mutex mu;                    // guards lanes, free_lanes
     std::vector<bpg_lane *> lanes;
+    std::vector<bpg_lane *> free_lanes;   // lanes of threads that have exited: the next new thread takes one over
 };
 
 namespace bpg {
@@ -160,6 +163,9 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
 // table holds W * npts records with records [0, npts) filled: fills [w * npts + i] = 2^(c w) P_i
 int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int W);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);
+int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, size_t stride, int rows, size_t np, size_t m,
+                    msm_fixed_base fb, aniels_rec *d_tab, bpg_msm_job **out_job);
+int msm_fold_wait(bpg_msm_job *job);
 int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]);
 void msm_job_destroy(bpg_msm_job *job);
 }  // namespace bpg

@@ -886,6 +886,130 @@ __global__ void __launch_bounds__(320) k_tail_b(const ge_rec *__restrict__ chunk
     }
 }
 
+// ------------------------------------------------------------------ folded generators
+// G'_i = sum_{j = i mod m} s_j G_j (and H' likewise): 2m sums per scalar row [s_G (np) | s_H (np)], each over
+// np / m generators with full-size scalars, from the fixed-base table (window w of point j is one record).
+// A signed c-bit digit d is cut into 5-bit pieces |d| = p0 + 32 p1 + 1024 p2 (c <= 15), and the window's point
+// goes, with d's sign, into bucket (target, piece t, p_t): 3 x 32 buckets per target.  The sort, accumulate and
+// merge kernels above then run on those bucket numbers, k_tail_a turns every 32-bucket set into
+// sum_b (b+1) B_b = total + sum_j 2^j S_j, and k_fold_finish joins the three sets (x 32, x 1024) into one point
+// and writes it as an affine Niels record, ready to be a point of a variable-base MSM.
+__device__ __forceinline__ uint32_t fold_target(uint32_t row, uint32_t i, uint32_t np, uint32_t m) {
+    const uint32_t side = i >= np ? 1u : 0u, jj = i - side * np;
+    return (row * 2u + side) * m + (jj & (m - 1u));
+}
+// bins of 256 buckets = 8 piece sets; one tile (a run of indices of one row, one side, one window) reaches the
+// m * 96 / 256 bins of its (row, side), which is what the LDS cursors cover
+__global__ void __launch_bounds__(512) k_fold_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ bin_counts, size_t n,
+                                                   int W, uint32_t np, uint32_t m, int tile) {
+    extern __shared__ uint32_t lds[];
+    const int w = blockIdx.y, row = blockIdx.z;
+    const int16_t *dg = digits + ((size_t)row * W + w) * n;
+    const uint32_t start = blockIdx.x * (uint32_t)tile, end = start + tile < n ? start + tile : (uint32_t)n;
+    const uint32_t nb = m * 96u / 256u;                      // bins per (row, side)
+    const uint32_t binbase = ((uint32_t)row * 2u + (start >= np ? 1u : 0u)) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
+    __syncthreads();
+    for (uint32_t i0 = start; i0 < end; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const int d = i < end ? dg[i] : 0;
+        const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t pc = (a >> (5 * t)) & 31u;
+            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+            (void)lds_claim(lds, (g >> 8) - binbase, pc != 0);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t c = lds[b];
+        if (c) atomicAdd(&bin_counts[binbase + b], c);
+    }
+}
+__global__ void __launch_bounds__(512) k_fold_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ bin_off,
+                                                      uint32_t *__restrict__ bin_fill, uint2 *__restrict__ tmp, size_t n, int W,
+                                                      uint32_t np, uint32_t m, int tile) {
+    extern __shared__ uint32_t lds[];
+    const int w = blockIdx.y, row = blockIdx.z;
+    const int16_t *dg = digits + ((size_t)row * W + w) * n;
+    const uint32_t start = blockIdx.x * (uint32_t)tile, end = start + tile < n ? start + tile : (uint32_t)n;
+    const uint32_t nb = m * 96u / 256u;
+    const uint32_t binbase = ((uint32_t)row * 2u + (start >= np ? 1u : 0u)) * nb;
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
+    __syncthreads();
+    for (uint32_t i0 = start; i0 < end; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const int d = i < end ? dg[i] : 0;
+        const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t pc = (a >> (5 * t)) & 31u;
+            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+            (void)lds_claim(lds, (g >> 8) - binbase, pc != 0);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+        const uint32_t c = lds[b];
+        if (c) lds[b] = bin_off[binbase + b] + atomicAdd(&bin_fill[binbase + b], c);
+    }
+    __syncthreads();
+    for (uint32_t i0 = start; i0 < end; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const int d = i < end ? dg[i] : 0;
+        const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+        const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
+        const uint32_t entry = i | ((uint32_t)w << 26) | (d < 0 ? 0x80000000u : 0u);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t pc = (a >> (5 * t)) & 31u;
+            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+            const uint32_t pos = lds_claim(lds, (g >> 8) - binbase, pc != 0);
+            if (pc != 0) tmp[pos] = make_uint2(entry, g & 255u);
+        }
+    }
+}
+// sets: [target][piece][total, S_0 .. S_4] as k_tail_a leaves them (NB = 32); one thread per target
+__global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ sets, uint32_t ntargets, aniels_rec *__restrict__ tab) {
+    const uint32_t tg = blockIdx.x * 256u + threadIdx.x;
+    if (tg >= ntargets) return;
+    ge p;
+    for (int t = 2; t >= 0; t--) {
+        const ge_rec *base = sets + ((size_t)tg * 3 + t) * 6;
+        ge v, x;
+        load_ge(v, base + 5);
+        for (int j = 3; j >= 0; j--) {
+            ge_double(v, v);
+            load_ge(x, base + 1 + j);
+            ge_add(v, v, x);
+        }
+        load_ge(x, base);
+        ge_add(v, v, x);
+        if (t == 2) {
+            p = v;
+        } else {
+            for (int k = 0; k < 5; k++) ge_double(p, p);
+            ge_add(p, p, v);
+        }
+    }
+    fe zinv;
+    fe_invert(zinv, p.Z);
+    ge_aniels r;
+    ge_to_aniels(r, p, zinv);
+    uint4 *o = reinterpret_cast<uint4 *>(tab + tg);
+    o[0] = make_uint4(r.YpX.v[0], r.YpX.v[1], r.YpX.v[2], r.YpX.v[3]);
+    o[1] = make_uint4(r.YpX.v[4], r.YpX.v[5], r.YpX.v[6], r.YpX.v[7]);
+    o[2] = make_uint4(r.YmX.v[0], r.YmX.v[1], r.YmX.v[2], r.YmX.v[3]);
+    o[3] = make_uint4(r.YmX.v[4], r.YmX.v[5], r.YmX.v[6], r.YmX.v[7]);
+    o[4] = make_uint4(r.T2d.v[0], r.T2d.v[1], r.T2d.v[2], r.T2d.v[3]);
+    o[5] = make_uint4(r.T2d.v[4], r.T2d.v[5], r.T2d.v[6], r.T2d.v[7]);
+    o[6] = make_uint4(0, 0, 0, 0);
+    o[7] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------ host side
 
 static int ilog2(size_t x) {
@@ -921,7 +1045,10 @@ int fixed_base_windows(int c) { return windows_for(c); }
 
 msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float density, int resident_lanes) {
     msm_plan pl{};
-    int c = auto_window(n);
+    // density: the fraction of a target's scalars that are non-zero (block-diagonal rows over a union of tables)
+    size_t n_eff = n;
+    if (!fixed_c && density > 0.f && density < 1.f) n_eff = (size_t)((double)n * density) + 1;
+    int c = auto_window(n_eff);
     if (tune.c >= 2 && tune.c <= 14) c = tune.c;
     if (fixed_c) c = fixed_c;
     pl.c = c;
@@ -931,7 +1058,6 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float d
     // S0 = entries per accumulate thread (any integer).  Measured: shrinking S0 so that a proof-sized MSM's threads
     // just fill the machine does not pay -- the pass is bound by total additions once two waves share a SIMD, and
     // more partials make the merge passes longer.
-    (void)density;
     (void)resident_lanes;
     pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 256) ? tune.ls0 : 16;
     pl.ls1 = (tune.ls1 >= 1 && tune.ls1 <= 8) ? tune.ls1 : 4;
@@ -1191,6 +1317,136 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
+    return BPG_OK;
+}
+
+// Folded generators (see k_fold_hist): rows scalar rows [s_G (np) | s_H (np)] `stride` scalars apart, the fixed-base
+// tables of G[0..np) and H[0..np) in segs[0], segs[1]; writes rows * 2m affine Niels records
+// [row][G'_0 .. G'_{m-1} | H'_0 .. H'_{m-1}] to d_tab (device).  Asynchronous: msm_fold_wait(job).
+int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, size_t stride, int rows, size_t np, size_t m,
+                    msm_fixed_base fb, aniels_rec *d_tab, bpg_msm_job **out_job) {
+    if (!ctx || !segs || !d_scalars || !d_tab || !out_job || rows < 1) return BPG_EINVAL;
+    if (fb.c < 2 || fb.c > 14 || !fb.wstride) return BPG_EINVAL;                      // three 5-bit pieces cover |d| <= 2^13
+    if (np < m || m < 32 || (m & (m - 1)) || (np & (np - 1)) || np > ((size_t)1 << 25)) return BPG_EINVAL;
+    if (segs[0].len != np || segs[1].len != np || !segs[0].base || !segs[1].base) return BPG_EINVAL;
+    const size_t n = 2 * np;
+    if (stride < n || stride >= ((size_t)1 << 32)) return BPG_EINVAL;
+    bpg_lane *lane = lane_of(ctx);
+    if (!lane) return BPG_EDEVICE;
+    bpg_msm_job *j = acquire_job(lane);
+    if (!j) return BPG_EDEVICE;
+    const int c = fb.c, W = windows_for(c);
+    const int S0 = 16, LS1 = 4;
+    const size_t ntargets = (size_t)rows * 2 * m, sets = ntargets * 3;
+    const size_t NE = sets * 32;                           // buckets
+    const size_t M = (size_t)rows * 3 * W * n;             // upper bound on entries
+    if (M >= ((size_t)1 << 32) || NE >= ((size_t)1 << 30)) return BPG_EINVAL;
+    // merge passes: a bucket holds at most (np / m) * W entries
+    const size_t worst = (np / m) * (size_t)W;
+    int R = 0;
+    while (((size_t)S0 << (LS1 * R)) < worst) R++;
+    const int nlevels = R + 1;
+    if (nlevels > MAX_LEVELS) return BPG_EINVAL;
+    int tile = 4096;
+    if ((size_t)tile > np) tile = (int)np;                 // a tile never straddles the G / H boundary
+    const int ntiles = (int)(n / tile);
+    const size_t nblk = (NE + 1023) / 1024;
+    const size_t NBT = NE / 256;                           // bins of 256 buckets
+    const uint32_t CH = 12288;
+    const int LOWN = 256;
+    const size_t NCH = M / CH + NBT;
+    size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS], part_total = 0;
+    cap_lv[0] = M / (size_t)S0 + NE + 1;
+    for (int r = 1; r < nlevels; r++) {
+        const size_t by_count = ((M / (size_t)S0) >> (r * LS1)) + NE + 1;
+        cap_lv[r] = cap_lv[r - 1] / 2 + 1 < by_count ? cap_lv[r - 1] / 2 + 1 : by_count;
+    }
+    for (int r = 0; r < nlevels; r++) {
+        part_off[r] = part_total;
+        part_total += cap_lv[r];
+    }
+    const size_t lvl_words = NE + nblk + 1;
+    const size_t map_words = cap_lv[0] + (nlevels > 1 ? cap_lv[1] : 0);
+    int rc;
+    if ((rc = grow((void **)&j->d_out, &j->cap_out, sets * 6 * sizeof(ge_rec)))) return rc;
+    if ((rc = grow((void **)&j->d_digits, &j->cap_digits, (size_t)rows * W * n * sizeof(int16_t)))) return rc;
+    if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
+    if ((rc = grow((void **)&j->d_counts, &j->cap_counts,
+                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 4 * NBT + NCH * (size_t)LOWN + 16) * sizeof(uint32_t))))
+        return rc;
+    if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, M * sizeof(uint2) + 64))) return rc;
+    if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
+    j->busy = true;
+    j->plan = msm_plan{};
+    j->plan.n = 0;                                         // nothing for msm_wait to fold on the host
+    *out_job = j;
+    hipStream_t s = j->stream;
+    BPG_CHECK_HIP(hipEventRecord(j->ev[0], s));
+    seg_map map{};
+    sc_map smap{};
+    for (int k = 0; k < 4; k++) {
+        map.base[k] = k < 2 ? segs[k].base - (size_t)k * np : nullptr;
+        map.len[k] = k < 2 ? (uint32_t)((k + 1) * np) : 0xffffffffu;
+        smap.off[k] = k < 2 ? (uint32_t)segs[k].sc_off : 0u;
+        smap.end[k] = map.len[k];
+    }
+    smap.stride = stride;
+    uint32_t *counts = j->d_counts, *ent_off = counts + NE;
+    uint32_t *lvl_base = ent_off + NE;
+    auto lv_local = [&](int idx) { return lvl_base + (size_t)idx * lvl_words; };
+    auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
+    uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
+    uint32_t *bin_counts = map0 + map_words, *bin_fill = bin_counts + NBT, *bin_off = bin_fill + NBT;
+    uint32_t *chunk_off = bin_off + NBT + 1, *chunk_hist = chunk_off + NBT + 1;
+    uint2 *tmp = (uint2 *)j->d_tmp;
+    dispatch_digits(c, s, (const uint32_t *)d_scalars, j->d_digits, n, (size_t)rows * n, smap, bin_counts, (uint32_t)(2 * NBT));
+    dim3 tgrid(ntiles, W, rows);
+    const size_t bin_lds = (m * 96 / 256) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_fold_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, W, (uint32_t)np, (uint32_t)m, tile);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, chunk_off, (uint32_t)NBT, CH);
+    hipLaunchKernelGGL(k_fold_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, W, (uint32_t)np,
+                       (uint32_t)m, tile);
+    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
+                       j->d_entries, (uint32_t)NBT, CH, LOWN);
+    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(NBT < 512 ? NBT : 512)), dim3(256), 0, s, bin_off, chunk_off, chunk_hist, counts,
+                       ent_off, (uint32_t)NBT, LOWN);
+    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(NCH < 2048 ? NCH : 2048)), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist,
+                       ent_off, j->d_entries, (uint32_t)NBT, CH, LOWN);
+    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, S0, LS1);
+    hipLaunchKernelGGL(k_scan_b, dim3(nlevels + 1), dim3(1024), 0, s, lvl_base, lvl_words, NE, nblk);
+    levels_dev L{};
+    L.nlevels = nlevels;
+    for (int r = 0; r < nlevels; r++) {
+        L.lv[r] = level_ref{lv_local(r + 1), lv_tot(r + 1)};
+        L.parts[r] = j->d_partials + part_off[r];
+    }
+    hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
+                       map0, map1, (uint32_t)NE, S0, LS1);
+    if (lane->acc_gate_job && lane->acc_gate_job != j) BPG_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
+    BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
+    hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts, ent_off,
+                       L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, S0, map, (uint32_t)fb.wstride);
+    BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
+    lane->acc_gate_job = j;
+    for (int r = 1; r < nlevels; r++) {
+        const uint32_t *mp = r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr;
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r], mp,
+                           j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r, S0, LS1);
+    }
+    // every piece set is one 32-bucket "window": [total, S_0 .. S_4] per set
+    // (grid: 64 sets in y, the rest in z -- m >= 32 makes the set count a multiple of 64; the kernel's window index is z * 64 + y)
+    hipLaunchKernelGGL(k_tail_a, dim3(1, 64, (unsigned)(sets / 64)), dim3(32), (size_t)32 * 128, s, L, counts, j->d_out, 32, 32, 5, 64,
+                       S0, LS1);
+    hipLaunchKernelGGL(k_fold_finish, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, j->d_out, (uint32_t)ntargets, d_tab);
+    BPG_CHECK_HIP(hipGetLastError());
+    BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
+    return BPG_OK;
+}
+
+int msm_fold_wait(bpg_msm_job *j) {
+    if (!j || !j->busy) return BPG_EINVAL;
+    BPG_CHECK_HIP(hipEventSynchronize(j->ev[3]));
+    j->busy.store(false, std::memory_order_release);
     return BPG_OK;
 }
 

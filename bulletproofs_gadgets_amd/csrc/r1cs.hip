@@ -834,6 +834,12 @@ ConstraintSystem::Triple Prover::allocate_multiplier(const Scalar *left, const S
     return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
 }
 
+// Inner-product round after which finish_group materializes the folded generators (0: never; BPG_IPP_FOLD
+// overrides): when 2 x 2048 folded generators are left.  The fold costs about 3.4 rounds' worth of additions
+// whenever it is done; measured at 2^16 multipliers, 16 threads x 8 statements: 204-210 proofs/s without,
+// 211 / 246 / 242 after round 4 / 5 / 6.
+static int ipp_fold_default(size_t lg) { return lg >= 12 ? (int)lg - 11 : 0; }
+
 static inline size_t next_pow2(size_t n) {
     size_t p = 1;
     while (p < n) p <<= 1;
@@ -967,7 +973,13 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     // ---- device workspace
     const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
     const size_t nblk_n = grid256(n ? n : 1), nblk_np = grid256(np);
-    size_t need = pad256(g * 3 * N1 * 32) + pad256(g * 2 * NR * 32) + (1 << 16);
+    // materialize the folded generators after round k0 (see msm_fold_submit): later rounds run on 2m points per proof
+    int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg) : ctx->tune.ipp_fold;
+    if (gens->world != 1 || k0 < 1 || (size_t)k0 >= lg || (np >> k0) < 32) k0 = 0;
+    const size_t fm = k0 ? np >> k0 : 0;                  // folded generators per side
+    // MSM scalar rows: 2g rows of NR before the fold, of g * 2 fm + 1 after it
+    const size_t row_words = std::max(g * 2 * NR, 2 * g * (g * 2 * fm + 1));
+    size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256(g * 2 * fm * 128) + (1 << 16);
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         build_flat_plan(p.cs_, (uint32_t)n, (uint32_t)p.v_.size(), false, pf[j].fp);
@@ -979,7 +991,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     int rc = ar.reserve(need);
     if (rc) return rc;
     sc *d_rows_all = ar.take<sc>(g * 3 * N1);             // proof j: rows 3j .. 3j+2
-    sc *d_rowLR_all = ar.take<sc>(g * 2 * NR);            // proof j: rows 2j, 2j+1
+    sc *d_rowLR_all = ar.take<sc>(row_words);             // proof j: rows 2j, 2j+1
+    sc *d_s_all = ar.take<sc>(g * 2 * np);                // proof j: [sG (np) | sH (np)]
+    aniels_rec *d_tab_all = (aniels_rec *)ar.take<uint8_t>(g * 2 * fm * 128 + 128);   // proof j: [G' (fm) | H' (fm)]
     BPG_CHECK_HIP(hipMemsetAsync(d_rows_all, 0, g * 3 * N1 * 32, s));
     std::vector<std::vector<sc>> keep_sL(g), keep_sR(g);  // pageable sources of async copies: alive until the sync
     for (size_t j = 0; j < g; j++) {
@@ -1120,8 +1134,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.w = p.tr_.challenge_scalar("w");
         f.d_a = ar.take<sc>(np);
         f.d_b = ar.take<sc>(np);
-        f.d_sG = ar.take<sc>(np);
-        f.d_sH = ar.take<sc>(np);
+        f.d_sG = d_s_all + j * 2 * np;
+        f.d_sH = f.d_sG + np;
         f.d_cpart = ar.take<sc>(nblk_np * 2);
         f.d_rowLR = d_rowLR_all + j * 2 * NR;
         hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, f.x.v, f.u.v, f.d_l1, f.d_aO,
@@ -1137,18 +1151,54 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     const double t3 = now_ms();
     size_t nk = np;
     std::vector<uint8_t> lr(64 * g);
+    // until the fold: vectors over the np original generators, rows [G | H | B] of NR scalars.  After it: over
+    // the fm folded ones of each proof; the group's tables form one point set [tab_0 | .. | tab_{g-1} | B] and
+    // proof j's two rows are zero outside its own block, so one variable-base MSM still serves the group.
+    size_t cnp = np, cstride = NR, cblk = nblk_np;
+    std::vector<sc> ones;
     for (size_t k = 0; k < lg; k++, nk >>= 1) {
+        if (k0 && k == (size_t)k0) {
+            BPG_CHECK_HIP(hipStreamSynchronize(s));         // the folds of round k-1 wrote sG / sH
+            msm_seg fs[2] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np)};
+            bpg_msm_job *job = nullptr;
+            if ((rc = msm_fold_submit(ctx, fs, d_s_all, 2 * np, (int)g, np, fm, msm_fixed_base{gens->fb_c, gens->npoints(), 1.f},
+                                      d_tab_all, &job)))
+                return rc;
+            if ((rc = msm_fold_wait(job))) return rc;
+            cnp = fm;
+            cstride = g * 2 * fm + 1;
+            cblk = grid256(fm);
+            ones.assign(fm, sc_one());
+            BPG_CHECK_HIP(hipMemsetAsync(d_rowLR_all, 0, 2 * g * cstride * 32, s));
+            for (size_t j = 0; j < g; j++) {
+                PF &f = pf[j];
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sG, ones.data(), fm * 32, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sH, ones.data(), fm * 32, hipMemcpyHostToDevice, s));
+                f.d_rowLR = d_rowLR_all + 2 * j * cstride + j * 2 * fm;
+            }
+        }
+        const size_t boff = cnp == np ? 2 * np : cstride - 1;        // where a row keeps the scalar of B
         for (size_t j = 0; j < g; j++) {
             PF &f = pf[j];
-            hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, f.d_a, f.d_b, f.d_sG,
-                               f.d_sH, f.d_rowLR, f.d_rowLR + NR, f.d_cpart);
-            hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, f.d_cpart, (uint32_t)nblk_np, f.w.v, f.d_rowLR + 2 * np,
-                               f.d_rowLR + NR + 2 * np);
+            sc *rowL = f.d_rowLR, *rowR = f.d_rowLR + cstride;
+            sc *row0 = cnp == np ? rowL : d_rowLR_all + 2 * j * cstride;
+            hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, f.d_a, f.d_b, f.d_sG,
+                               f.d_sH, rowL, rowR, f.d_cpart);
+            hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, f.d_cpart, (uint32_t)cblk, f.w.v, row0 + boff, row0 + cstride + boff);
         }
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(hipStreamSynchronize(s));
-        msm_seg segs[3] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np), pedersen_seg(gens, 0, 1, 2 * np)};
-        if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f))) return rc;     // half of every row is zero
+        if (cnp == np) {
+            msm_seg segs[3] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np), pedersen_seg(gens, 0, 1, 2 * np)};
+            if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f))) return rc;     // half of every row is zero
+        } else {
+            msm_seg segs[2] = {msm_seg{d_tab_all, g * 2 * fm, 0}, pedersen_seg(gens, 0, 1, g * 2 * fm)};
+            bpg_msm_job *job = nullptr;
+            if ((rc = msm_submit(ctx, segs, 2, d_rowLR_all, cstride, (int)(2 * g), false, &job,
+                                 msm_fixed_base{0, 0, 1.f / (float)(2 * g)}, 0)))
+                return rc;
+            if ((rc = msm_wait(job, lr.data(), false))) return rc;
+        }
         for (size_t j = 0; j < g; j++) {
             Prover &p = *ps[j];
             PF &f = pf[j];
@@ -1159,7 +1209,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             p.tr_.append_point("L", o);
             p.tr_.append_point("R", o + 32);
             const Scalar uk = p.tr_.challenge_scalar("u"), uk_inv = uk.invert();
-            hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)np, (uint32_t)nk, uk.v, uk_inv.v, f.d_a,
+            hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)cblk), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, uk.v, uk_inv.v, f.d_a,
                                f.d_b, f.d_sG, f.d_sH);
         }
         BPG_CHECK_HIP(hipGetLastError());
