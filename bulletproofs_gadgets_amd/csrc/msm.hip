@@ -891,8 +891,8 @@ __global__ void __launch_bounds__(320) k_tail_b(const ge_rec *__restrict__ chunk
 // np / m generators with full-size scalars, from the fixed-base table (window w of point j is one record).
 // A signed c-bit digit d is cut into 5-bit pieces |d| = p0 + 32 p1 + 1024 p2 (c <= 15), and the window's point
 // goes, with d's sign, into bucket (target, piece t, p_t): 3 x 32 buckets per target.  The sort, accumulate and
-// merge kernels above then run on those bucket numbers, k_tail_a turns every 32-bucket set into
-// sum_b (b+1) B_b = total + sum_j 2^j S_j, and k_fold_finish joins the three sets (x 32, x 1024) into one point
+// merge kernels above then run on those bucket numbers, k_fold_sets turns every 32-bucket set into
+// sum_b (b+1) B_b, and k_fold_finish joins the three sets (x 32, x 1024) into one point
 // and writes it as an affine Niels record, ready to be a point of a variable-base MSM.
 __device__ __forceinline__ uint32_t fold_target(uint32_t row, uint32_t i, uint32_t np, uint32_t m) {
     const uint32_t side = i >= np ? 1u : 0u, jj = i - side * np;
@@ -972,22 +972,33 @@ __global__ void __launch_bounds__(512) k_fold_scatter(const int16_t *__restrict_
         }
     }
 }
-// sets: [target][piece][total, S_0 .. S_4] as k_tail_a leaves them (NB = 32); one thread per target
+// one thread per piece set: sum_b (b + 1) B_b over its 32 buckets by running sums (a 32-thread bit tree per set,
+// k_tail_a's way, took 1.9 ms for the 98 k sets of eight 2^16-multiplier proofs; this takes a tenth)
+__global__ void __launch_bounds__(256) k_fold_sets(levels_dev L, const uint32_t *__restrict__ counts, uint32_t nsets,
+                                                  ge_rec *__restrict__ out, int ls0, int ls1) {
+    const uint32_t st = blockIdx.x * 256u + threadIdx.x;
+    if (st >= nsets) return;
+    ge run, acc, b;
+    ge_identity(run);
+    ge_identity(acc);
+    for (int k = 31; k >= 0; k--) {
+        const size_t g = (size_t)st * 32 + k;
+        if (counts[g]) {
+            bucket_sum(b, L, counts, g, ls0, ls1);
+            ge_add(run, run, b);
+        }
+        ge_add(acc, acc, run);
+    }
+    store_ge(out + st, acc);
+}
+// sets: [target][piece] as k_fold_sets leaves them; one thread per target
 __global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ sets, uint32_t ntargets, aniels_rec *__restrict__ tab) {
     const uint32_t tg = blockIdx.x * 256u + threadIdx.x;
     if (tg >= ntargets) return;
     ge p;
     for (int t = 2; t >= 0; t--) {
-        const ge_rec *base = sets + ((size_t)tg * 3 + t) * 6;
-        ge v, x;
-        load_ge(v, base + 5);
-        for (int j = 3; j >= 0; j--) {
-            ge_double(v, v);
-            load_ge(x, base + 1 + j);
-            ge_add(v, v, x);
-        }
-        load_ge(x, base);
-        ge_add(v, v, x);
+        ge v;
+        load_ge(v, sets + (size_t)tg * 3 + t);
         if (t == 2) {
             p = v;
         } else {
@@ -1433,10 +1444,7 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r], mp,
                            j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r, S0, LS1);
     }
-    // every piece set is one 32-bucket "window": [total, S_0 .. S_4] per set
-    // (grid: 64 sets in y, the rest in z -- m >= 32 makes the set count a multiple of 64; the kernel's window index is z * 64 + y)
-    hipLaunchKernelGGL(k_tail_a, dim3(1, 64, (unsigned)(sets / 64)), dim3(32), (size_t)32 * 128, s, L, counts, j->d_out, 32, 32, 5, 64,
-                       S0, LS1);
+    hipLaunchKernelGGL(k_fold_sets, dim3((unsigned)((sets + 255) / 256)), dim3(256), 0, s, L, counts, (uint32_t)sets, j->d_out, S0, LS1);
     hipLaunchKernelGGL(k_fold_finish, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, j->d_out, (uint32_t)ntargets, d_tab);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
