@@ -182,9 +182,22 @@ __global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, sc x, sc 
 //   G_j (idx = j mod n_k): idx >= half -> L gets a[idx-half] * sG_j, else R gets a[idx+half] * sG_j
 //   H_j:                   idx <  half -> L gets b[idx+half] * sH_j, else R gets b[idx-half] * sH_j
 // partial[block] = per-block sums of (c_L, c_R) terms, c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo>.
-__global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, const sc *__restrict__ a, const sc *__restrict__ b,
-                                                  const sc *__restrict__ sG, const sc *__restrict__ sH, sc *__restrict__ rowL,
-                                                  sc *__restrict__ rowR, sc *__restrict__ partial) {
+// The three round kernels serve a group of up to 8 proofs per launch (blockIdx.y = proof): alone they are
+// launch-bound (17 us for 2048 elements), and a group's rounds are in lock-step anyway.
+struct ipp_proof {
+    sc *a, *b, *sG, *sH;       // the proof's vectors
+    sc *rowL, *rowR;           // its block of the L / R scalar rows
+    sc *cpart;                 // per-block partial sums of (c_L, c_R)
+    sc *outL, *outR;           // where the rows keep the scalar of B
+    sc w, u, uinv;             // Q = w B; the round's challenge and its inverse
+};
+struct ipp_group {
+    ipp_proof p[8];
+};
+__global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, const ipp_group G) {
+    const ipp_proof &P = G.p[blockIdx.y];
+    const sc *__restrict__ a = P.a, *__restrict__ b = P.b, *__restrict__ sG = P.sG, *__restrict__ sH = P.sH;
+    sc *__restrict__ rowL = P.rowL, *__restrict__ rowR = P.rowR, *__restrict__ partial = P.cpart;
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     sc c[2] = {sc_zero(), sc_zero()};
     if (j < np) {
@@ -207,8 +220,11 @@ __global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, cons
 }
 
 // finish c_L, c_R and write the B-scalars  c_L * w,  c_R * w  (Q = w B)
-__global__ void __launch_bounds__(256) k_ipp_c(const sc *__restrict__ partial, uint32_t nblocks, sc w, sc *__restrict__ outL,
-                                               sc *__restrict__ outR) {
+__global__ void __launch_bounds__(256) k_ipp_c(uint32_t nblocks, const ipp_group G) {
+    const ipp_proof &P = G.p[blockIdx.y];
+    const sc *__restrict__ partial = P.cpart;
+    sc *__restrict__ outL = P.outL, *__restrict__ outR = P.outR;
+    const sc w = P.w;
     __shared__ sc res[2];
     sc c[2] = {sc_zero(), sc_zero()};
     for (uint32_t k = threadIdx.x; k < nblocks; k += 256) {
@@ -224,8 +240,10 @@ __global__ void __launch_bounds__(256) k_ipp_c(const sc *__restrict__ partial, u
 }
 
 // fold: a' = u a_lo + u^-1 a_hi, b' = u^-1 b_lo + u b_hi; sG_j *= (hi ? u : u^-1), sH_j *= (hi ? u^-1 : u)
-__global__ void __launch_bounds__(256) k_ipp_fold(uint32_t np, uint32_t nk, sc u, sc uinv, sc *__restrict__ a, sc *__restrict__ b,
-                                                  sc *__restrict__ sG, sc *__restrict__ sH) {
+__global__ void __launch_bounds__(256) k_ipp_fold(uint32_t np, uint32_t nk, const ipp_group G) {
+    const ipp_proof &P = G.p[blockIdx.y];
+    sc *__restrict__ a = P.a, *__restrict__ b = P.b, *__restrict__ sG = P.sG, *__restrict__ sH = P.sH;
+    const sc u = P.u, uinv = P.uinv;
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= np) return;
     const uint32_t half = nk >> 1, idx = j & (nk - 1);
@@ -1156,6 +1174,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     // proof j's two rows are zero outside its own block, so one variable-base MSM still serves the group.
     size_t cnp = np, cstride = NR, cblk = nblk_np;
     std::vector<sc> ones;
+    ipp_group grp{};
     for (size_t k = 0; k < lg; k++, nk >>= 1) {
         if (k0 && k == (size_t)k0) {
             BPG_CHECK_HIP(hipStreamSynchronize(s));         // the folds of round k-1 wrote sG / sH
@@ -1180,12 +1199,16 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         const size_t boff = cnp == np ? 2 * np : cstride - 1;        // where a row keeps the scalar of B
         for (size_t j = 0; j < g; j++) {
             PF &f = pf[j];
-            sc *rowL = f.d_rowLR, *rowR = f.d_rowLR + cstride;
-            sc *row0 = cnp == np ? rowL : d_rowLR_all + 2 * j * cstride;
-            hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, f.d_a, f.d_b, f.d_sG,
-                               f.d_sH, rowL, rowR, f.d_cpart);
-            hipLaunchKernelGGL(k_ipp_c, dim3(1), dim3(256), 0, s, f.d_cpart, (uint32_t)cblk, f.w.v, row0 + boff, row0 + cstride + boff);
+            sc *row0 = cnp == np ? f.d_rowLR : d_rowLR_all + 2 * j * cstride;
+            ipp_proof &q = grp.p[j];
+            q.a = f.d_a; q.b = f.d_b; q.sG = f.d_sG; q.sH = f.d_sH;
+            q.rowL = f.d_rowLR; q.rowR = f.d_rowLR + cstride;
+            q.cpart = f.d_cpart;
+            q.outL = row0 + boff; q.outR = row0 + cstride + boff;
+            q.w = f.w.v;
         }
+        hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, grp);
+        hipLaunchKernelGGL(k_ipp_c, dim3(1, (unsigned)g), dim3(256), 0, s, (uint32_t)cblk, grp);
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(hipStreamSynchronize(s));
         if (cnp == np) {
@@ -1201,7 +1224,6 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         }
         for (size_t j = 0; j < g; j++) {
             Prover &p = *ps[j];
-            PF &f = pf[j];
             R1CSProof &P = out[j];
             const uint8_t *o = &lr[64 * j];
             memcpy(&P.L_vec[32 * k], o, 32);
@@ -1209,9 +1231,10 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             p.tr_.append_point("L", o);
             p.tr_.append_point("R", o + 32);
             const Scalar uk = p.tr_.challenge_scalar("u"), uk_inv = uk.invert();
-            hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)cblk), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, uk.v, uk_inv.v, f.d_a,
-                               f.d_b, f.d_sG, f.d_sH);
+            grp.p[j].u = uk.v;
+            grp.p[j].uinv = uk_inv.v;
         }
+        hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, grp);
         BPG_CHECK_HIP(hipGetLastError());
     }
     std::vector<sc> hab(2 * g);
