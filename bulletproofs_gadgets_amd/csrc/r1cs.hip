@@ -118,11 +118,19 @@ __global__ void __launch_bounds__(256) k_dot_zpow(const uint32_t *__restrict__ t
 
 // l(X), r(X) coefficient vectors and the per-block partial sums of t1..t6
 //   l1 = a_L + y^-i wR   l2 = a_O   l3 = s_L      r0 = wO - y^i   r1 = y^i a_R + wL   r3 = y^i s_R
-__global__ void __launch_bounds__(256) k_poly(uint32_t n, const sc *__restrict__ aL, const sc *__restrict__ aR,
-                                              const sc *__restrict__ aO, const sc *__restrict__ sL, const sc *__restrict__ sR,
-                                              const sc *__restrict__ W, const sc *__restrict__ ytbl,
-                                              const sc *__restrict__ yinvtbl, sc *__restrict__ l1, sc *__restrict__ r0,
-                                              sc *__restrict__ r1, sc *__restrict__ r3, sc *__restrict__ partial) {
+// (k_poly and k_eval, like the round kernels further down, take a group of up to 8 proofs: blockIdx.y = proof)
+struct poly_proof {
+    const sc *aL, *aR, *aO, *sL, *sR, *W, *ytbl, *yinvtbl;
+    sc *l1, *r0, *r1, *r3, *partial;
+};
+struct poly_group {
+    poly_proof p[8];
+};
+__global__ void __launch_bounds__(256) k_poly(uint32_t n, const poly_group G) {
+    const poly_proof &P = G.p[blockIdx.y];
+    const sc *__restrict__ aL = P.aL, *__restrict__ aR = P.aR, *__restrict__ aO = P.aO, *__restrict__ sL = P.sL,
+                          *__restrict__ sR = P.sR, *__restrict__ W = P.W, *__restrict__ ytbl = P.ytbl, *__restrict__ yinvtbl = P.yinvtbl;
+    sc *__restrict__ l1 = P.l1, *__restrict__ r0 = P.r0, *__restrict__ r1 = P.r1, *__restrict__ r3 = P.r3, *__restrict__ partial = P.partial;
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     sc t[6];
 #pragma unroll
@@ -151,11 +159,20 @@ __global__ void __launch_bounds__(256) k_poly(uint32_t n, const sc *__restrict__
 
 // l(x), r(x) -> the IPP's a, b (length np, padded), and the generator factor vectors
 //   sG_j = G_factors[j] = 1 (j < n) | u (pad)      sH_j = y^-j * G_factors[j]
-__global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, sc x, sc u, const sc *__restrict__ l1,
-                                              const sc *__restrict__ aO, const sc *__restrict__ sL, const sc *__restrict__ r0,
-                                              const sc *__restrict__ r1, const sc *__restrict__ r3,
-                                              const sc *__restrict__ ytbl, const sc *__restrict__ yinvtbl, sc *__restrict__ a,
-                                              sc *__restrict__ b, sc *__restrict__ sG, sc *__restrict__ sH) {
+struct eval_proof {
+    sc x, u;
+    const sc *l1, *aO, *sL, *r0, *r1, *r3, *ytbl, *yinvtbl;
+    sc *a, *b, *sG, *sH;
+};
+struct eval_group {
+    eval_proof p[8];
+};
+__global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, const eval_group G) {
+    const eval_proof &P = G.p[blockIdx.y];
+    const sc x = P.x, u = P.u;
+    const sc *__restrict__ l1 = P.l1, *__restrict__ aO = P.aO, *__restrict__ sL = P.sL, *__restrict__ r0 = P.r0, *__restrict__ r1 = P.r1,
+                          *__restrict__ r3 = P.r3, *__restrict__ ytbl = P.ytbl, *__restrict__ yinvtbl = P.yinvtbl;
+    sc *__restrict__ a = P.a, *__restrict__ b = P.b, *__restrict__ sG = P.sG, *__restrict__ sH = P.sH;
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= np) return;
     sc yinvi = pow_tbl(yinvtbl, i);
@@ -1059,6 +1076,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
     // ---- challenges y, z; flatten, l/r polynomials, t coefficients
     const double t2 = now_ms();
+    poly_group pgrp{};
+    eval_group egrp{};
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         PF &f = pf[j];
@@ -1093,12 +1112,16 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.d_part = ar.take<sc>(nblk_n * 6);
         f.h_part.resize(nblk_n * 6);
         f.wV.resize(m);
-        if (n) {
-            hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n), dim3(256), 0, s, (uint32_t)n, f.d_aL, f.d_aR, f.d_aO, f.d_sL, f.d_sR, f.d_W,
-                               f.d_ytbl, f.d_yinvtbl, f.d_l1, f.d_r0, f.d_r1, f.d_r3, f.d_part);
-            BPG_CHECK_HIP(hipGetLastError());
-            BPG_CHECK_HIP(hipMemcpyAsync(f.h_part.data(), f.d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
-        }
+        pgrp.p[j] = poly_proof{f.d_aL, f.d_aR, f.d_aO, f.d_sL, f.d_sR, f.d_W, f.d_ytbl, f.d_yinvtbl, f.d_l1, f.d_r0, f.d_r1, f.d_r3, f.d_part};
+    }
+    if (n) {
+        hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n, (unsigned)g), dim3(256), 0, s, (uint32_t)n, pgrp);
+        BPG_CHECK_HIP(hipGetLastError());
+    }
+    for (size_t j = 0; j < g; j++) {
+        PF &f = pf[j];
+        const size_t m = ps[j]->v_.size();
+        if (n) BPG_CHECK_HIP(hipMemcpyAsync(f.h_part.data(), f.d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
         if (m) BPG_CHECK_HIP(hipMemcpyAsync(f.wV.data(), f.d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
     }
     BPG_CHECK_HIP(hipStreamSynchronize(s));
@@ -1156,13 +1179,13 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.d_sH = f.d_sG + np;
         f.d_cpart = ar.take<sc>(nblk_np * 2);
         f.d_rowLR = d_rowLR_all + j * 2 * NR;
-        hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, f.x.v, f.u.v, f.d_l1, f.d_aO,
-                           f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH);
-        BPG_CHECK_HIP(hipGetLastError());
+        egrp.p[j] = eval_proof{f.x.v, f.u.v, f.d_l1, f.d_aO, f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH};
         p.tr_.innerproduct_domain_sep(np);
         P.L_vec.assign(32 * lg, 0);
         P.R_vec.assign(32 * lg, 0);
     }
+    hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np, (unsigned)g), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, egrp);
+    BPG_CHECK_HIP(hipGetLastError());
     const double poly_ms = (now_ms() - t2) / (double)g;
 
     // ---- inner-product argument, fold-free: one 2g-target MSM per round
