@@ -1388,11 +1388,21 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, M * sizeof(uint2) + 64))) return rc;
     if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
     j->busy = true;
+    // a HIP failure below must not leave the job marked busy for ever
+#define FOLD_CHECK_HIP(expr)                                  \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) {                               \
+            bpg::set_last_error(#expr, _e);                   \
+            j->busy.store(false, std::memory_order_release);  \
+            return BPG_EDEVICE;                               \
+        }                                                     \
+    } while (0)
     j->plan = msm_plan{};
     j->plan.n = 0;                                         // nothing for msm_wait to fold on the host
     *out_job = j;
     hipStream_t s = j->stream;
-    BPG_CHECK_HIP(hipEventRecord(j->ev[0], s));
+    FOLD_CHECK_HIP(hipEventRecord(j->ev[0], s));
     seg_map map{};
     sc_map smap{};
     for (int k = 0; k < 4; k++) {
@@ -1433,11 +1443,11 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     }
     hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
                        map0, map1, (uint32_t)NE, S0, LS1);
-    if (lane->acc_gate_job && lane->acc_gate_job != j) BPG_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
-    BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
+    if (lane->acc_gate_job && lane->acc_gate_job != j) FOLD_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
+    FOLD_CHECK_HIP(hipEventRecord(j->ev[1], s));
     hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts, ent_off,
                        L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, S0, map, (uint32_t)fb.wstride);
-    BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
+    FOLD_CHECK_HIP(hipEventRecord(j->ev[2], s));
     lane->acc_gate_job = j;
     for (int r = 1; r < nlevels; r++) {
         const uint32_t *mp = r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr;
@@ -1446,9 +1456,10 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     }
     hipLaunchKernelGGL(k_fold_sets, dim3((unsigned)((sets + 255) / 256)), dim3(256), 0, s, L, counts, (uint32_t)sets, j->d_out, S0, LS1);
     hipLaunchKernelGGL(k_fold_finish, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, j->d_out, (uint32_t)ntargets, d_tab);
-    BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
+    FOLD_CHECK_HIP(hipGetLastError());
+    FOLD_CHECK_HIP(hipEventRecord(j->ev[3], s));
     return BPG_OK;
+#undef FOLD_CHECK_HIP
 }
 
 int msm_fold_wait(bpg_msm_job *j) {
