@@ -14,15 +14,17 @@ mkdir -p build
 HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=${ARCH} -Wall -Wno-unused-function -Iinclude"
 
 objs=()
+pids=()
 for f in ${SRC}/*.hip; do
     o=build/$(basename "${f%.hip}").o
     if [[ ! -f $o || $f -nt $o || -n $(find ${SRC} include -name '*.h' -newer "$o" -print -quit) ]]; then
         echo "hipcc $f"
-        $HIPCC $HIPFLAGS -c "$f" -o "$o" &
+        ( $HIPCC $HIPFLAGS -c "$f" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
+        pids+=($!)
     fi
     objs+=("$o")
 done
-wait
+for p in "${pids[@]}"; do wait "$p"; done      # a failed compile stops the build (set -e): never link a stale object
 $HIPCC -shared -fPIC --offload-arch=${ARCH} -o ${OUT}/libbpg.so "${objs[@]}" -Wl,-rpath,/opt/rocm/lib -lpthread
 echo "built ${OUT}/libbpg.so"
 

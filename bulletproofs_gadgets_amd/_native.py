@@ -67,6 +67,7 @@ def lib():
         "bpg_msm_combine_partials": (ctypes.c_int, [cp, sz, vp]),
         "bpg_msm_plan": (ctypes.c_int, [vp, sz, sz, ip, ip, ip, ip]),
         "bpg_msm_last_kernel_us": (ctypes.c_int, [vp, fp, fp]),
+        "bpg_debug_fail_alloc": (None, [ctypes.c_int]),
     }
     u64p, dp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)
     ci = ctypes.c_int
@@ -96,6 +97,7 @@ def lib():
         "bpg_cs_multiply": (ci, [vp, u64p, cp, sz, u64p, cp, sz, u64p]),
         "bpg_cs_allocate_multiplier": (ci, [vp, cp, cp, u64p]),
         "bpg_cs_constrain": (ci, [vp, u64p, cp, sz]),
+        "bpg_cs_export_terms": (ci, [vp, u64p, vp, ctypes.POINTER(ctypes.c_uint32), sz, psz]),
         "bpg_gadget_binary_constrain": (ci, [vp, ctypes.c_uint64]),
         "bpg_gadget_nonzero": (ci, [vp, u64p, cp, sz, cp]),
         "bpg_point_from_coords": (ci, [cp, pvp]),

@@ -163,13 +163,13 @@ bpg_lane *lane_of(bpg_ctx *ctx) {
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n) {
     if (!n) return BPG_OK;
     BPG_LANE(ctx);
-    uint8_t *d_in = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
+    int rc;
+    if ((rc = grow(&lane->d_io, &lane->io_cap, n * 64))) return rc;
+    uint8_t *d_in = (uint8_t *)lane->d_io;
     BPG_CHECK_HIP(hipMemcpyAsync(d_in, host64, n * 64, hipMemcpyHostToDevice, lane->stream));
     hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-    (void)hipFree(d_in);
     return BPG_OK;
 }
 
@@ -177,18 +177,16 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
     *n_bad = 0;
     if (!n) return BPG_OK;
     BPG_LANE(ctx);
-    uint8_t *d_in = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
-    uint32_t *d_flag = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_flag, 4));
+    int rc;
+    if ((rc = grow(&lane->d_io, &lane->io_cap, n * 32 + 256))) return rc;
+    uint8_t *d_in = (uint8_t *)lane->d_io;
+    uint32_t *d_flag = (uint32_t *)(d_in + n * 32);
     BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, lane->stream));
     BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, lane->stream));
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n, d_flag);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(n_bad, d_flag, 4, hipMemcpyDeviceToHost, lane->stream));
     BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-    (void)hipFree(d_in);
-    (void)hipFree(d_flag);
     return BPG_OK;
 }
 
@@ -286,6 +284,18 @@ int bpg_init(int device_id, bpg_ctx **out) {
         return BPG_EDEVICE;
     }
     if (device_id < 0 || device_id >= count) return BPG_EINVAL;
+    {
+        // the kernels are built for gfx950 (MI355X) only: anything else would fail at the first launch
+        hipDeviceProp_t prop;
+        BPG_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "bpg_init: device %d is %s; this library is built for gfx950 (MI355X) only", device_id,
+                     prop.gcnArchName);
+            set_last_error_msg(msg);
+            return BPG_EDEVICE;
+        }
+    }
     BPG_CHECK_HIP(hipSetDevice(device_id));
     // BPG_SYNC=block: host threads sleep in stream / event waits instead of spinning (many prover
     // threads per GPU share the host cores with circuit capture and the transcript's Keccak chain)
@@ -326,6 +336,7 @@ void bpg_shutdown(bpg_ctx *ctx) {
         (void)hipStreamSynchronize(lane->stream);
         if (lane->ws) (void)hipFree(lane->ws);
         if (lane->d_dyn) (void)hipFree(lane->d_dyn);
+        if (lane->d_io) (void)hipFree(lane->d_io);
         (void)hipStreamDestroy(lane->stream);
         delete lane;
     }
@@ -382,19 +393,11 @@ int bpg_points_from_compressed(bpg_ctx *ctx, const uint8_t *points32, size_t n, 
     int rc = points_alloc(ctx, n, &p);
     if (rc) return rc;
     if (n) {
-        uint8_t *d_in = nullptr;
-        uint32_t *d_bad = nullptr;
         uint32_t bad = 0;
-        BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 32));
-        BPG_CHECK_HIP(hipMalloc((void **)&d_bad, 4));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_in, points32, n * 32, hipMemcpyHostToDevice, lane->stream));
-        BPG_CHECK_HIP(hipMemsetAsync(d_bad, 0, 4, lane->stream));
-        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, p->d_table, n, d_bad);
-        BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, lane->stream));
-        BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-        (void)hipFree(d_in);
-        (void)hipFree(d_bad);
+        if ((rc = table_write_compressed(ctx, p->d_table, points32, n, &bad))) {
+            bpg_points_free(p);
+            return rc;
+        }
         if (bad) {
             bpg_points_free(p);
             set_last_error_msg("bpg_points_from_compressed: invalid ristretto255 encoding");
@@ -411,14 +414,9 @@ int bpg_points_from_uniform(bpg_ctx *ctx, const uint8_t *uniform64, size_t n, bp
     bpg_points *p = nullptr;
     int rc = points_alloc(ctx, n, &p);
     if (rc) return rc;
-    if (n) {
-        uint8_t *d_in = nullptr;
-        BPG_CHECK_HIP(hipMalloc((void **)&d_in, n * 64));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_in, uniform64, n * 64, hipMemcpyHostToDevice, lane->stream));
-        hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, p->d_table, n);
-        BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-        (void)hipFree(d_in);
+    if (n && (rc = table_write_uniform(ctx, p->d_table, uniform64, n))) {
+        bpg_points_free(p);
+        return rc;
     }
     *out = p;
     return BPG_OK;
@@ -428,13 +426,13 @@ int bpg_points_compress(bpg_ctx *ctx, const bpg_points *pts, size_t start, size_
     if (!ctx || !pts || (n && !out32) || start + n > pts->n) return BPG_EINVAL;
     if (!n) return BPG_OK;
     BPG_LANE(ctx);
-    uint8_t *d_out = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_out, n * 32));
+    int rc;
+    if ((rc = grow(&lane->d_io, &lane->io_cap, n * 32))) return rc;
+    uint8_t *d_out = (uint8_t *)lane->d_io;
     hipLaunchKernelGGL(k_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, pts->d_table + start, d_out, n);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_out, n * 32, hipMemcpyDeviceToHost, lane->stream));
     BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-    (void)hipFree(d_out);
     return BPG_OK;
 }
 
@@ -494,6 +492,8 @@ int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int
     if (threads_per_bucket) *threads_per_bucket = pl.P;
     return BPG_OK;
 }
+
+void bpg_debug_fail_alloc(int countdown) { bpg::debug_fail_alloc(countdown); }
 
 int bpg_msm_last_kernel_us(bpg_ctx *ctx, float *accumulate_us, float *total_device_us) {
     if (!ctx) return BPG_EINVAL;

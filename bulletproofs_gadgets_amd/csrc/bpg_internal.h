@@ -69,6 +69,9 @@ int fixed_base_window(size_t points);
 int fixed_base_windows(int c);
 
 int grow(void **p, size_t *cap, size_t need);
+// hipMalloc behind the fault-injection hook of bpg_debug_fail_alloc (every growable workspace goes through it)
+hipError_t device_malloc(void **p, size_t bytes);
+void debug_fail_alloc(int countdown);
 
 inline void ge_load(ge &p, const ge_rec &r) {
     for (int i = 0; i < 8; i++) {
@@ -123,6 +126,10 @@ struct bpg_lane {
     // per-proof points of a verification (commitments, proof points), decoded to affine Niels
     bpg::aniels_rec *d_dyn = nullptr;
     size_t dyn_cap = 0;
+    // staging of the small codec / Pedersen kernels (inputs and outputs of one call; grown on demand, never freed
+    // per call: hipFree is a device-wide synchronisation, and 24 prover threads share the GPU)
+    void *d_io = nullptr;
+    size_t io_cap = 0;
 };
 
 struct bpg_ctx {

@@ -93,19 +93,19 @@ struct SonnyEdwardsPointGadget {
         return {LC(oX), LC(oY), LC(oZ), LC(oT)};
     }
 
-    // ref: edwards_point.rs:215-253
+    // ref: edwards_point.rs:215-253.  In the Rust, `let (bit, _, ..)` inside the y' and z' blocks shadows `bit`
+    // only within each block (:227, :237): the third multiply (bit * Z, :237) and the fourth (T * bit, :246)
+    // take the right wire of the FIRST multiply (:221) again; the inner wires only appear in y' and z'.
     SonnyEdwardsPointGadget conditionally_select(const LC &bit_lc, ConstraintSystem &cs) const {
         LC one(Scalar(1));
         auto m1 = cs.multiply(X, bit_lc);                       // (_, bit, x')
-        Variable bit = m1.r;
-        auto m2 = cs.multiply(LC(bit), Y);                      // (bit, _, bit*y)
-        bit = m2.l;
-        LC y_prime = LC(m2.o) + one - LC(bit);
-        cs.constrain(y_prime - LC(m2.o) - one + LC(bit));
-        auto m3 = cs.multiply(LC(bit), Z);
-        bit = m3.l;
-        LC z_prime = LC(m3.o) + one - LC(bit);
-        cs.constrain(z_prime - LC(m3.o) - one + LC(bit));
+        const Variable bit = m1.r;
+        auto m2 = cs.multiply(LC(bit), Y);                      // (bit_y, _, bit*y)
+        LC y_prime = LC(m2.o) + one - LC(m2.l);
+        cs.constrain(y_prime - LC(m2.o) - one + LC(m2.l));
+        auto m3 = cs.multiply(LC(bit), Z);                      // (bit_z, _, bit*z)
+        LC z_prime = LC(m3.o) + one - LC(m3.l);
+        cs.constrain(z_prime - LC(m3.o) - one + LC(m3.l));
         auto m4 = cs.multiply(T, LC(bit));
         return {LC(m1.o), y_prime, z_prime, LC(m4.o)};
     }

@@ -1103,13 +1103,27 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float d
     return pl;
 }
 
+// bpg_debug_fail_alloc(k): the k-th device allocation from now on (1 = the next one) fails as if the GPU were
+// out of memory; 0 disarms.  For the tests of the failure paths (no 288 GB allocation needed to get there).
+static std::atomic<int> g_fail_alloc{0};
+void debug_fail_alloc(int countdown) { g_fail_alloc.store(countdown); }
+hipError_t device_malloc(void **p, size_t bytes) {
+    int c = g_fail_alloc.load();
+    while (c > 0 && !g_fail_alloc.compare_exchange_weak(c, c - 1)) {}
+    if (c == 1) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
+}
+
 int grow(void **p, size_t *cap, size_t need) {
     if (need <= *cap) return BPG_OK;
     if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
     size_t want = need + need / 8 + 256;
-    BPG_CHECK_HIP(hipMalloc(p, want));
+    BPG_CHECK_HIP(device_malloc(p, want));
     *cap = want;
     return BPG_OK;
 }
@@ -1141,7 +1155,10 @@ static bpg_msm_job *acquire_job(bpg_lane *lane) {
         return nullptr;
     }
     for (auto &e : j->ev)
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        if (hipEventCreate(&e) != hipSuccess) {
+            msm_job_destroy(j);                     // frees the stream and the events created so far
+            return nullptr;
+        }
     lane->jobs.push_back(j);
     return j;
 }
@@ -1194,6 +1211,16 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     if (!lane) return BPG_EDEVICE;
     bpg_msm_job *j = acquire_job(lane);
     if (!j) return BPG_EDEVICE;
+    // The job is ours from here on.  Whatever fails below (a device allocation, a HIP call), it goes back to the
+    // lane's pool: its stream orders anything already launched before the job's next use, and its buffers stay
+    // owned by it.  *out_job is only set on success.
+    j->busy.store(true, std::memory_order_release);
+    struct Release {
+        bpg_msm_job *j;
+        ~Release() {
+            if (j) j->busy.store(false, std::memory_order_release);
+        }
+    } release{j};
     msm_plan pl = make_plan(n, T, ctx->tune, fb.c, fb.density, ctx->resident_lanes);
     j->plan = pl;
     const size_t NE = (size_t)T * pl.Wb * pl.NB;          // buckets
@@ -1214,14 +1241,14 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         BPG_CHECK_HIP(hipHostMalloc((void **)&j->h_out, want, hipHostMallocDefault));
         j->cap_hout = want;
     }
-    j->busy = true;
-    *out_job = j;
     hipStream_t s = j->stream;
     BPG_CHECK_HIP(hipEventRecord(j->ev[0], s));
     if (n == 0) {
         BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
         BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
         BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
+        release.j = nullptr;
+        *out_job = j;
         return BPG_OK;
     }
     // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
@@ -1328,6 +1355,8 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
+    release.j = nullptr;
+    *out_job = j;
     return BPG_OK;
 }
 

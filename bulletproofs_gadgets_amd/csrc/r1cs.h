@@ -183,7 +183,9 @@ struct ConstraintStore {
     uint32_t num_constraints = 0;
     uint32_t id_one = 0xffffffffu, id_minus_one = 0xffffffffu;       // almost every coefficient is +1 or -1
     uint32_t intern(const sc &c);
-    void push(const LinearCombination &lc);
+    // n_mult / n_commit: multipliers allocated and values committed so far; a term outside them throws
+    // R1CSError(BPG_EINVAL) (a gadget built from another constraint system's variables)
+    void push(const LinearCombination &lc, size_t n_mult, size_t n_commit);
 };
 
 class ConstraintSystem {
@@ -195,6 +197,10 @@ class ConstraintSystem {
     virtual Triple allocate_multiplier(const Scalar *left, const Scalar *right) = 0;
     virtual void constrain(const LinearCombination &lc) = 0;
     virtual bool is_prover() const = 0;
+    // what a Variable may refer to: multipliers allocated and values committed so far
+    virtual size_t num_multipliers() const = 0;
+    virtual size_t num_committed() const = 0;
+    virtual const ConstraintStore &store() const = 0;
 };
 
 // ---- generators ----------------------------------------------------------------
@@ -252,7 +258,7 @@ class Prover : public ConstraintSystem {
     void commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, uint8_t *V32, Variable *vars);
     Triple multiply(LinearCombination left, LinearCombination right) override;
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
-    void constrain(const LinearCombination &lc) override { cs_.push(lc); }
+    void constrain(const LinearCombination &lc) override { cs_.push(lc, a_L_.size(), v_.size()); }
     bool is_prover() const override { return true; }
     Scalar eval(const LinearCombination &lc) const;
     // Prover::prove(bp_gens); returns BPG_OK or a negative BPG_E* code
@@ -261,7 +267,9 @@ class Prover : public ConstraintSystem {
     // asked in the same order), but the blinding RNGs of up to eight provers of one circuit shape are drawn in
     // lock-step (TranscriptRngLanes8), which is where most of a proof's host time goes.
     static int prove_many(Prover *const *provers, size_t k, rng_fill_fn rng, void *rng_user, R1CSProof *out);
-    size_t num_multipliers() const { return a_L_.size(); }
+    size_t num_multipliers() const override { return a_L_.size(); }
+    size_t num_committed() const override { return v_.size(); }
+    const ConstraintStore &store() const override { return cs_; }
     size_t num_constraints() const { return cs_.num_constraints; }
     Transcript &transcript() { return tr_; }
     struct Timing { double rng_ms = 0, commit_ms = 0, poly_ms = 0, ipp_ms = 0, total_ms = 0; } timing;
@@ -287,6 +295,7 @@ class Prover : public ConstraintSystem {
 struct VerifyRow {
     sc *d_sc = nullptr;
     size_t np = 0;
+    sc rho;                      // batching weight of this equation (verify_batch)
     std::vector<sc> tail;
     std::vector<uint8_t> dyn;
 };
@@ -297,12 +306,14 @@ class Verifier : public ConstraintSystem {
     Variable commit(const uint8_t V32[32]);
     Triple multiply(LinearCombination left, LinearCombination right) override;
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
-    void constrain(const LinearCombination &lc) override { cs_.push(lc); }
+    void constrain(const LinearCombination &lc) override { cs_.push(lc, num_vars_, V_.size() / 32); }
     bool is_prover() const override { return false; }
     // Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng); BPG_OK or BPG_EVERIFY / BPG_EGENS / ...
     int verify(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user);
     int prepare(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user, VerifyRow &out);
-    size_t num_multipliers() const { return num_vars_; }
+    size_t num_multipliers() const override { return num_vars_; }
+    size_t num_committed() const override { return V_.size() / 32; }
+    const ConstraintStore &store() const override { return cs_; }
     size_t num_constraints() const { return cs_.num_constraints; }
 
   private:

@@ -436,7 +436,11 @@ uint32_t ConstraintStore::intern(const sc &c) {
     return (uint32_t)coeffs.size() - 1;
 }
 
-void ConstraintStore::push(const LinearCombination &lc) {
+void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_commit) {
+    for (const auto &t : lc.terms) {
+        const size_t lim = t.var.kind == VAR_COMMITTED ? n_commit : t.var.kind == VAR_ONE ? 1 : t.var.kind <= VAR_OUTPUT ? n_mult : 0;
+        if (t.var.index >= lim) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
+    }
     for (const auto &t : lc.terms) {
         term_var.push_back(t.var.kind << 28 | t.var.index);
         term_coeff.push_back(intern(t.coeff.v));
@@ -522,7 +526,7 @@ struct Arena {
         lane->ws = nullptr;
         lane->ws_cap = 0;
         size_t want = bytes + bytes / 4 + (1 << 20);
-        BPG_CHECK_HIP(hipMalloc(&lane->ws, want));
+        BPG_CHECK_HIP(device_malloc(&lane->ws, want));
         lane->ws_cap = want;
         return BPG_OK;
     }
@@ -641,16 +645,17 @@ static size_t flatten_bytes(const ConstraintStore &cs, const FlatPlan &fp) {
 
 // =================================================================== generators
 
-struct GensExtra {
-    aniels_rec *d_comb = nullptr;     // 2 x 64 x 8 comb table for B, B~
-};
-
 int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, exchange_fn exchange, void *exchange_user) {
     if (!ctx || !out || capacity == 0 || capacity > ((size_t)1 << 26)) return BPG_EINVAL;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !exchange)) return BPG_EINVAL;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
-    Gens *g = new Gens();
+    // everything allocated below is released by gens_destroy on every failure path
+    struct Guard {
+        Gens *g;
+        ~Guard() { gens_destroy(g); }
+    } guard{new Gens()};
+    Gens *g = guard.g;
     g->ctx = ctx;
     g->capacity = capacity;
     g->rank = rank;
@@ -663,16 +668,14 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, 
     tbl->ctx = ctx;
     tbl->n = g->npoints();
     tbl->d_table = nullptr;
+    g->table = tbl;
     g->fb_c = fixed_base_window(tbl->n);
     g->fb_windows = fixed_base_windows(g->fb_c);
-    hipError_t e = hipMalloc((void **)&tbl->d_table, (size_t)g->fb_windows * tbl->n * sizeof(aniels_rec));
+    hipError_t e = device_malloc((void **)&tbl->d_table, (size_t)g->fb_windows * tbl->n * sizeof(aniels_rec));
     if (e != hipSuccess) {
         set_last_error("hipMalloc(generator table)", e);
-        delete tbl;
-        delete g;
         return BPG_ENOMEM;
     }
-    g->table = tbl;
     // BulletproofGens::new(capacity, 1): GeneratorsChain = SHAKE256("GeneratorsChain" | label), label = 'G'/'H' | u32le(0).
     // The XOF stream is sequential: a rank squeezes past the generators it does not hold.
     const size_t CH = (size_t)1 << 16;
@@ -704,12 +707,11 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, 
     s3.squeeze(h, 64);
     if ((rc = table_write_uniform(ctx, tbl->d_table + g->off_Bb(), h, 1))) return rc;
     if ((rc = table_build_shifted(ctx, tbl->d_table, tbl->n, g->fb_c, g->fb_windows))) return rc;
-    GensExtra ex;
-    BPG_CHECK_HIP(hipMalloc((void **)&ex.d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
-    hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), ex.d_comb);
+    BPG_CHECK_HIP(device_malloc(&g->d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
+    hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), (aniels_rec *)g->d_comb);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
-    g->d_comb = ex.d_comb;
+    guard.g = nullptr;
     *out = g;
     return BPG_OK;
 }
@@ -724,23 +726,22 @@ void gens_destroy(Gens *g) {
     delete g;
 }
 
-// m Pedersen commitments (K3); scalars = [m][2] host; out32 host
+// m Pedersen commitments (K3); scalars = [m][2] host; out32 host.  Staging lives in the lane (grown on demand):
+// no hipMalloc / hipFree per call -- hipFree synchronises the whole device under every other prover thread.
 static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     if (!m) return BPG_OK;
     bpg_lane *lane = lane_of(g->ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
-    sc *d_s = nullptr;
-    uint8_t *d_o = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_s, m * 64));
-    BPG_CHECK_HIP(hipMalloc((void **)&d_o, m * 32));
+    int rc;
+    if ((rc = grow(&lane->d_io, &lane->io_cap, m * 96))) return rc;
+    sc *d_s = (sc *)lane->d_io;
+    uint8_t *d_o = (uint8_t *)lane->d_io + m * 64;
     BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d_s);
-    (void)hipFree(d_o);
     return BPG_OK;
 }
 
@@ -830,6 +831,8 @@ Scalar Prover::eval(const LinearCombination &lc) const {
     Scalar acc(0);
     for (const auto &t : lc.terms) {
         const sc *val;
+        const size_t lim = t.var.kind == VAR_COMMITTED ? v_.size() : t.var.kind == VAR_ONE ? 1 : t.var.kind <= VAR_OUTPUT ? a_L_.size() : 0;
+        if (t.var.index >= lim) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
         switch (t.var.kind) {
             case VAR_LEFT: val = &a_L_[t.var.index]; break;
             case VAR_RIGHT: val = &a_R_[t.var.index]; break;
@@ -855,8 +858,8 @@ ConstraintSystem::Triple Prover::multiply(LinearCombination left, LinearCombinat
     a_O_.push_back(o.v);
     left.terms.push_back({t.l, -Scalar(1)});
     right.terms.push_back({t.r, -Scalar(1)});
-    cs_.push(left);
-    cs_.push(right);
+    cs_.push(left, a_L_.size(), v_.size());
+    cs_.push(right, a_L_.size(), v_.size());
     return t;
 }
 
@@ -1295,8 +1298,8 @@ ConstraintSystem::Triple Verifier::multiply(LinearCombination left, LinearCombin
     Triple t{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
     left.terms.push_back({t.l, -Scalar(1)});
     right.terms.push_back({t.r, -Scalar(1)});
-    cs_.push(left);
-    cs_.push(right);
+    cs_.push(left, num_vars_, V_.size() / 32);
+    cs_.push(right, num_vars_, V_.size() / 32);
     return t;
 }
 
@@ -1356,6 +1359,9 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     rng_fn(rng_user, ext, 32);
     rng.finalize(ext);
     const Scalar r = rng.scalar();
+    // second draw of the same RNG: the weight of this proof's equation in a batch (verify_batch).  It is bound to
+    // the whole transcript (statement and proof) and to the external randomness, like r itself.
+    out.rho = rng.scalar();
 
     // per-proof points -> this lane's point scratch: [A_I1 A_O1 S1 A_I2 A_O2 S2 | V.. | T.. | L.. | R..]
     const size_t ndyn = 6 + m + 5 + 2 * lg;
@@ -1440,12 +1446,19 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     if ((rc = msm_submit(ctx, gh, 2, d_gh, gh[0].len + gh[1].len, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()},
                          ng + nh)))
         return rc;
-    if (gens->rank == 0 && (rc = msm_submit(ctx, rest, 2, d_tail, 2 + ndyn, 1, false, &job_d))) return rc;
+    // From here on job_f's kernels read the lane's arena (d_gh): whatever happens to the second job, the first is
+    // waited on before this function returns and the caller reuses or frees those buffers.
     uint8_t parts[256], out[32];
-    if ((rc = msm_wait(job_f, parts, true))) return rc;
+    int rc_d = BPG_OK;
+    if (gens->rank == 0) rc_d = msm_submit(ctx, rest, 2, d_tail, 2 + ndyn, 1, false, &job_d);
+    rc = msm_wait(job_f, parts, true);
     if (job_d) {
-        if ((rc = msm_wait(job_d, parts + 128, true))) return rc;
-    } else {
+        const int rc2 = msm_wait(job_d, parts + 128, true);      // reads d_tail and the lane's point scratch
+        if (!rc) rc = rc2;
+    }
+    if (rc_d) return rc_d;
+    if (rc) return rc;
+    if (!job_d) {
         memset(parts + 128, 0, 128);          // identity: (0, 1, 1, 0)
         parts[128 + 32] = 1;
         parts[128 + 64] = 1;
@@ -1474,8 +1487,10 @@ int Verifier::verify(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *r
     return verify_msm(lane, gens, row.d_sc, row.np, row.np, row.d_sc + 2 * row.np, row.tail, row.dyn);
 }
 
-// One combined multiscalar multiplication for k proofs: sum_j rho_j * (verification equation j)
-// with rho_j drawn from the caller's RNG.  BPG_OK iff every proof verifies (up to 2^-250).
+// One combined multiscalar multiplication for k proofs: sum_j rho_j * (verification equation j).  rho_j is the second
+// draw (after r) of verifier j's TranscriptRng, which has absorbed proof j's whole transcript and 32 bytes of the
+// caller's RNG: a weight is never zero and never independent of the proof it weighs, whatever the caller's RNG
+// returns.  BPG_OK iff every proof verifies (up to 2^-250 with a real external RNG).
 int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *gens, rng_fill_fn rng_fn, void *rng_user) {
     if (!k) return BPG_OK;
     bpg_lane *lane = lane_of(gens->ctx);
@@ -1500,13 +1515,11 @@ int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *g
         VerifyRow row;
         int rc = vs[j]->prepare(proofs[j], gens, rng_fn, rng_user, row);
         if (rc) return rc;
-        uint8_t wide[64] = {0};
-        rng_fn(rng_user, wide, 32);
-        sc lo, hi, rho_sc;
-        sc_frombytes(lo, wide);
-        sc_frombytes(hi, wide + 32);
-        sc_reduce512(rho_sc, lo, hi);
-        const Scalar rho = j == 0 ? Scalar(1) : Scalar(rho_sc);
+        const Scalar rho(row.rho);
+        if (rho.is_zero()) {                                  // probability 2^-252 with a working RNG: refuse rather than skip a proof
+            set_last_error_msg("verify_batch: zero batching weight (broken external RNG?)");
+            return BPG_EINVAL;
+        }
         hipLaunchKernelGGL(k_axpy, dim3(grid256(row.np)), dim3(256), 0, s, (uint32_t)row.np, rho.v, row.d_sc, d_acc);
         hipLaunchKernelGGL(k_axpy, dim3(grid256(row.np)), dim3(256), 0, s, (uint32_t)row.np, rho.v, row.d_sc + row.np, d_acc + cap);
         BPG_CHECK_HIP(hipGetLastError());

@@ -35,10 +35,29 @@ uint64_t pack_var(const Variable &v) { return (uint64_t)v.kind << 32 | v.index; 
 // Scalar::from_bytes_mod_order
 Scalar sc_in(const uint8_t *b) { return Scalar::from_bytes(b); }
 
-LC unpack_lc(const uint64_t *vars, const uint8_t *coeffs, size_t n) {
+// A variable that crosses the ABI is checked against the constraint system it is used with: the kind must be one
+// of the five, a multiplier index must have been allocated and a commitment index committed.  (An index past the
+// end would write past the flattening plan's slot table and read past the witness vectors.)
+Variable checked_var(const ConstraintSystem &cs, uint64_t packed) {
+    const Variable v = unpack_var(packed);
+    bool ok;
+    switch (v.kind) {
+        case VAR_COMMITTED: ok = v.index < cs.num_committed(); break;
+        case VAR_LEFT:
+        case VAR_RIGHT:
+        case VAR_OUTPUT: ok = v.index < cs.num_multipliers(); break;
+        case VAR_ONE: ok = v.index == 0; break;
+        default: ok = false;
+    }
+    if (!ok) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
+    return v;
+}
+
+LC unpack_lc(const ConstraintSystem &cs, const uint64_t *vars, const uint8_t *coeffs, size_t n) {
+    if (n && (!vars || !coeffs)) throw R1CSError(BPG_EINVAL, "linear combination: null arrays");
     LC lc;
     lc.terms.reserve(n);
-    for (size_t i = 0; i < n; i++) lc.terms.push_back({unpack_var(vars[i]), sc_in(coeffs + 32 * i)});
+    for (size_t i = 0; i < n; i++) lc.terms.push_back({checked_var(cs, vars[i]), sc_in(coeffs + 32 * i)});
     return lc;
 }
 
@@ -252,7 +271,7 @@ int bpg_cs_multiply(bpg_cs *cs, const uint64_t *lvars, const uint8_t *lcoeffs, s
                     const uint8_t *rcoeffs, size_t nr, uint64_t out[3]) {
     if (!cs || !out) return BPG_EINVAL;
     return guarded([&] {
-        out_triple(out, cs->cs->multiply(unpack_lc(lvars, lcoeffs, nl), unpack_lc(rvars, rcoeffs, nr)));
+        out_triple(out, cs->cs->multiply(unpack_lc(*cs->cs, lvars, lcoeffs, nl), unpack_lc(*cs->cs, rvars, rcoeffs, nr)));
         return BPG_OK;
     });
 }
@@ -271,23 +290,37 @@ int bpg_cs_allocate_multiplier(bpg_cs *cs, const uint8_t *left32, const uint8_t 
 int bpg_cs_constrain(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n) {
     if (!cs) return BPG_EINVAL;
     return guarded([&] {
-        cs->cs->constrain(unpack_lc(vars, coeffs, n));
+        cs->cs->constrain(unpack_lc(*cs->cs, vars, coeffs, n));
         return BPG_OK;
     });
+}
+
+int bpg_cs_export_terms(const bpg_cs *cs, uint64_t *vars, uint8_t *coeffs32, uint32_t *constraint, size_t cap, size_t *n_terms) {
+    if (!cs || !n_terms) return BPG_EINVAL;
+    const ConstraintStore &st = cs->cs->store();
+    const size_t n = st.term_var.size();
+    *n_terms = n;
+    if (cap < n || (n && (!vars || !coeffs32 || !constraint))) return BPG_EINVAL;
+    for (size_t t = 0; t < n; t++) {
+        vars[t] = (uint64_t)(st.term_var[t] >> 28) << 32 | (st.term_var[t] & 0x0fffffffu);
+        sc_tobytes(coeffs32 + 32 * t, st.coeffs[st.term_coeff[t]]);
+        constraint[t] = st.term_q[t];
+    }
+    return BPG_OK;
 }
 
 // ---------------------------------------------------------------- gadgets
 int bpg_gadget_binary_constrain(bpg_cs *cs, uint64_t bit_var) {
     if (!cs) return BPG_EINVAL;
     return guarded([&] {
-        binary_constrain_gadget(*cs->cs, unpack_var(bit_var));
+        binary_constrain_gadget(*cs->cs, checked_var(*cs->cs, bit_var));
         return BPG_OK;
     });
 }
 int bpg_gadget_nonzero(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n, const uint8_t *assignment32) {
     if (!cs) return BPG_EINVAL;
     return guarded([&] {
-        LC lc = unpack_lc(vars, coeffs, n);
+        LC lc = unpack_lc(*cs->cs, vars, coeffs, n);
         if (assignment32) {
             Scalar a = sc_in(assignment32);
             nonzero_gadget(lc, &a, *cs->cs);
@@ -335,7 +368,7 @@ int bpg_edwards_conditionally_select(bpg_cs *cs, const bpg_point_gadget *a, cons
                                      size_t n, bpg_point_gadget **out) {
     if (!cs || !a || !out) return BPG_EINVAL;
     return guarded([&] {
-        auto r = E_OF(a).conditionally_select(unpack_lc(bit_vars, bit_coeffs, n), *cs->cs);
+        auto r = E_OF(a).conditionally_select(unpack_lc(*cs->cs, bit_vars, bit_coeffs, n), *cs->cs);
         *out = NEW_FROM(r);
         return BPG_OK;
     });
@@ -344,7 +377,7 @@ int bpg_edwards_scalar_mul(bpg_cs *cs, const bpg_point_gadget *point, const uint
     if (!cs || !point || !out || (nbits && !sk_vars)) return BPG_EINVAL;
     return guarded([&] {
         std::vector<Variable> sk(nbits);
-        for (size_t i = 0; i < nbits; i++) sk[i] = unpack_var(sk_vars[i]);
+        for (size_t i = 0; i < nbits; i++) sk[i] = checked_var(*cs->cs, sk_vars[i]);
         auto r = SonnyEdwardsPointGadget::scalar_mul(E_OF(point), sk, *cs->cs);
         *out = NEW_FROM(r);
         return BPG_OK;
@@ -414,7 +447,7 @@ int bpg_ristretto_conditionally_select(bpg_cs *cs, const bpg_point_gadget *a, co
                                        size_t n, bpg_point_gadget **out) {
     if (!cs || !a || !out) return BPG_EINVAL;
     return guarded([&] {
-        auto r = R_OF(a).conditionally_select(unpack_lc(bit_vars, bit_coeffs, n), *cs->cs);
+        auto r = R_OF(a).conditionally_select(unpack_lc(*cs->cs, bit_vars, bit_coeffs, n), *cs->cs);
         *out = NEW_FROM(r);
         return BPG_OK;
     });
@@ -424,7 +457,7 @@ int bpg_sk_knowledge_gadget(bpg_cs *cs, const bpg_point_gadget *basep, const bpg
     if (!cs || !basep || !pk || (nbits && !sk_vars)) return BPG_EINVAL;
     return guarded([&] {
         std::vector<Variable> sk(nbits);
-        for (size_t i = 0; i < nbits; i++) sk[i] = unpack_var(sk_vars[i]);
+        for (size_t i = 0; i < nbits; i++) sk[i] = checked_var(*cs->cs, sk_vars[i]);
         sk_knowledge_gadget(*cs->cs, R_OF(basep), R_OF(pk), sk);
         return BPG_OK;
     });

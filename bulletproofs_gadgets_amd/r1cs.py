@@ -7,6 +7,7 @@ that the parity tests read like the reference's own tests.  Every method is one
 call through the C ABI; nothing is computed here.
 """
 import ctypes
+import os
 
 from . import _native
 from ._native import BpgError, check, lib
@@ -90,16 +91,30 @@ class LinearCombination:
 LC = LinearCombination
 
 
-def _rng_cb(data):
-    """bpg_rng_fn that hands out `data` (the external randomness, e.g. 32 bytes from a seeded stream)."""
-    state = {"pos": 0}
+class _Rng:
+    """bpg_rng_fn over `data`: the external randomness of a call (the reference passes `&mut thread_rng()`,
+    ref: tests/edwards_point.rs:31,79).  data=None draws from os.urandom, which is what a caller who passes nothing
+    gets; a bytes object is handed out in order (seeded, reproducible runs) and a stream that runs out is an
+    error, raised by check() after the call returns -- never padded with zeros."""
 
-    def fn(_user, out, n):
-        chunk = data[state["pos"]:state["pos"] + n]
-        chunk = chunk + bytes(n - len(chunk))
-        state["pos"] += n
+    def __init__(self, data):
+        self.data, self.pos, self.short = data, 0, False
+        self.cb = _native.RNG_FN(self._fill)
+
+    def _fill(self, _user, out, n):
+        if self.data is None:
+            chunk = os.urandom(n)
+        else:
+            chunk = self.data[self.pos:self.pos + n]
+            self.pos += n
+            if len(chunk) < n:
+                self.short = True
+                chunk = os.urandom(n)      # the call still gets real randomness; its result is discarded below
         ctypes.memmove(out, chunk, n)
-    return _native.RNG_FN(fn)
+
+    def check(self):
+        if self.short:
+            raise ValueError("external randomness exhausted: %d bytes given, more were asked for" % len(self.data))
 
 
 class BulletproofGens:
@@ -174,6 +189,16 @@ class _CS:
         v, c, n = LinearCombination.of(lc).marshal()
         check(lib().bpg_cs_constrain(self._cs, v, c, n))
 
+    def export_terms(self):
+        """[(kind, index, coeff, constraint)] for every linear-combination term captured so far (bpg_cs_export_terms)"""
+        n = ctypes.c_size_t()
+        lib().bpg_cs_export_terms(self._cs, None, None, None, 0, ctypes.byref(n))
+        k = max(n.value, 1)
+        vars_, coeffs, q = (ctypes.c_uint64 * k)(), ctypes.create_string_buffer(32 * k), (ctypes.c_uint32 * k)()
+        check(lib().bpg_cs_export_terms(self._cs, vars_, coeffs, q, k, ctypes.byref(n)))
+        return [(vars_[t] >> 32, vars_[t] & 0xffffffff, int.from_bytes(coeffs.raw[32 * t:32 * t + 32], "little"), q[t])
+                for t in range(n.value)]
+
 
 class Prover(_CS):
     def __init__(self, gens, label):
@@ -205,26 +230,29 @@ class Prover(_CS):
         check(lib().bpg_prover_commit_batch(self._h, values32, blindings32, m, V, vars_))
         return V, vars_
 
-    def prove(self, bp_gens=None, external_rng32=bytes(32)):
+    def prove(self, bp_gens=None, external_rng32=None):
+        """external_rng32: 32 bytes of external randomness (None: os.urandom, as `thread_rng` in the reference)"""
         assert bp_gens is None or bp_gens is self.gens
-        cb = _rng_cb(external_rng32)
+        rng = _Rng(external_rng32)
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap)
         n = ctypes.c_size_t()
-        check(lib().bpg_prover_prove(self._h, cb, None, out, cap, ctypes.byref(n)))
+        check(lib().bpg_prover_prove(self._h, rng.cb, None, out, cap, ctypes.byref(n)))
+        rng.check()
         return Proof(out.raw[:n.value])
 
     @staticmethod
-    def prove_many(provers, external_rng=b""):
+    def prove_many(provers, external_rng=None):
         """k proofs by this thread (bpg_prover_prove_many): the bytes of [p.prove() for p in provers] when the
-        same external randomness stream (32 bytes per proof, in order) is used"""
+        same external randomness stream (32 bytes per proof, in order) is used; None: os.urandom"""
         k = len(provers)
-        cb = _rng_cb(external_rng)
+        rng = _Rng(external_rng)
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap * max(k, 1))
         lens = (ctypes.c_size_t * max(k, 1))()
         hs = (ctypes.c_void_p * max(k, 1))(*[p._h for p in provers])
-        check(lib().bpg_prover_prove_many(hs, k, cb, None, out, cap, lens))
+        check(lib().bpg_prover_prove_many(hs, k, rng.cb, None, out, cap, lens))
+        rng.check()
         return [Proof(out.raw[j * cap:j * cap + lens[j]]) for j in range(k)]
 
     def stats(self):
@@ -264,11 +292,13 @@ class Verifier(_CS):
         check(lib().bpg_verifier_commit_batch(self._h, V, m, vars_))
         return vars_
 
-    def verify(self, proof, pc_gens, bp_gens, external_rng32=bytes(32)):
-        """Ok(()) -> True; Err(R1CSError::VerificationError) -> raises VerificationError"""
+    def verify(self, proof, pc_gens, bp_gens, external_rng32=None):
+        """Ok(()) -> True; Err(R1CSError::VerificationError) -> raises VerificationError.
+        external_rng32: 32 bytes (None: os.urandom, as `&mut thread_rng()` at ref tests/edwards_point.rs:79)"""
         raw = proof.to_bytes() if hasattr(proof, "to_bytes") else bytes(proof)
-        cb = _rng_cb(external_rng32)
-        rc = lib().bpg_verifier_verify(self._h, bp_gens._h, raw, len(raw), cb, None)
+        rng = _Rng(external_rng32)
+        rc = lib().bpg_verifier_verify(self._h, bp_gens._h, raw, len(raw), rng.cb, None)
+        rng.check()
         if rc == _native.EVERIFY:
             raise VerificationError()
         check(rc)
@@ -288,9 +318,11 @@ class Verifier(_CS):
             pass
 
 
-def verify_batch(verifiers, proofs, bp_gens, external_rng=b""):
+def verify_batch(verifiers, proofs, bp_gens, external_rng=None):
     """k proofs, one combined multiscalar multiplication (BASELINE config 5).  True iff every proof
-    verifies; raises VerificationError if at least one does not.  external_rng: >= 64 * k bytes."""
+    verifies; raises VerificationError if at least one does not.  external_rng: None (os.urandom) or
+    >= 32 * k bytes, 32 per proof in order; the batching weights are derived inside the library from
+    each proof's transcript and these bytes, and are never zero."""
     k = len(verifiers)
     assert len(proofs) == k
     raws = [p.to_bytes() if hasattr(p, "to_bytes") else bytes(p) for p in proofs]
@@ -298,8 +330,9 @@ def verify_batch(verifiers, proofs, bp_gens, external_rng=b""):
     bufs = [ctypes.create_string_buffer(r, len(r)) for r in raws]
     ps = (ctypes.c_void_p * max(k, 1))(*[ctypes.addressof(b) for b in bufs])
     lens = (ctypes.c_size_t * max(k, 1))(*[len(r) for r in raws])
-    cb = _rng_cb(external_rng if len(external_rng) >= 64 * k else external_rng + bytes(64 * k - len(external_rng)))
-    rc = lib().bpg_verifier_verify_batch(vs, ps, lens, k, bp_gens._h, cb, None)
+    rng = _Rng(external_rng)
+    rc = lib().bpg_verifier_verify_batch(vs, ps, lens, k, bp_gens._h, rng.cb, None)
+    rng.check()
     if rc == _native.EVERIFY:
         raise VerificationError()
     check(rc)

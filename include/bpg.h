@@ -112,6 +112,11 @@ int bpg_msm_submit_segments(bpg_ctx *ctx, const bpg_points *pts, const size_t *s
 /* Diagnostics for bench.py: geometry the planner chose for (n, n_targets). */
 int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int *windows, int *buckets,
                  int *threads_per_bucket);
+/* Test hook, no counterpart in the reference: the k-th device allocation from now on (1 = the next one) made by a
+ * growable workspace of this library fails as if the GPU were out of memory; 0 disarms.  Lets the tests walk the
+ * failure paths of bpg_msm_submit / prove / verify without exhausting 288 GB. */
+void bpg_debug_fail_alloc(int countdown);
+
 /* Per-launch device time in microseconds of the bucket-accumulation kernel of
  * the most recently *waited* job, measured with HIP events on the job's stream. */
 int bpg_msm_last_kernel_us(bpg_ctx *ctx, float *accumulate_us, float *total_device_us);
@@ -190,21 +195,33 @@ int bpg_verifier_commit_batch(bpg_verifier *v, const uint8_t *V32, size_t m, uin
 /* Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng)   ref: tests/edwards_point.rs:79,158,242,345,412; scalar.rs:63; sk_know_gadget.rs:86
  * BPG_OK | BPG_EVERIFY (R1CSError::VerificationError) | BPG_EFORMAT | BPG_EGENS */
 int bpg_verifier_verify(bpg_verifier *v, bpg_gens *gens, const uint8_t *proof, size_t proof_len, bpg_rng_fn rng, void *rng_user);
-/* k proofs checked by ONE combined multiscalar multiplication: sum_j rho_j * (verification equation of proof j),
- * rho_j from `rng` (BASELINE config 5; SURVEY 8b bpg_r1cs_verify_batch).  Each verifier carries its own circuit and
- * commitments, as for bpg_verifier_verify, and is consumed the same way.  BPG_OK iff every proof verifies;
- * BPG_EVERIFY says at least one does not (verify them one by one to find which). */
+/* k proofs checked by ONE combined multiscalar multiplication: sum_j rho_j * (verification equation of proof j)
+ * (BASELINE config 5; SURVEY 8b bpg_r1cs_verify_batch).  `rng` is asked for 32 bytes per proof, in order, exactly as k
+ * bpg_verifier_verify calls would ask; rho_j is the second draw (after r) of verifier j's transcript RNG, so it is
+ * bound to proof j and to those 32 bytes and is never zero (BPG_EINVAL if it ever were).  Each verifier carries its
+ * own circuit and commitments, as for bpg_verifier_verify, and is consumed the same way.  BPG_OK iff every proof
+ * verifies; BPG_EVERIFY says at least one does not (verify them one by one to find which). */
 int bpg_verifier_verify_batch(bpg_verifier *const *verifiers, const uint8_t *const *proofs, const size_t *proof_lens, size_t k,
                               bpg_gens *gens, bpg_rng_fn rng, void *rng_user);
 int bpg_verifier_stats(const bpg_verifier *v, size_t *multipliers, size_t *constraints);
 
 /* ConstraintSystem::multiply / allocate_multiplier / constrain
  * (ref: edwards_point.rs:45-85; scalar.rs:10-21; boolean.rs:16,20).  out = (left, right, output) variables.
- * allocate_multiplier with NULL assignments on a prover returns BPG_EMISSING (R1CSError::MissingAssignment). */
+ * allocate_multiplier with NULL assignments on a prover returns BPG_EMISSING (R1CSError::MissingAssignment).
+ * Every variable of a linear combination is checked: BPG_EINVAL for an unknown kind, a multiplier index that this
+ * constraint system has not allocated, or a commitment index it has not committed (a variable of another prover,
+ * a stale handle); the Rust type system rules these out for the reference, its Prover panics on the index. */
 int bpg_cs_multiply(bpg_cs *cs, const uint64_t *lvars, const uint8_t *lcoeffs, size_t nl, const uint64_t *rvars,
                     const uint8_t *rcoeffs, size_t nr, uint64_t out[3]);
 int bpg_cs_allocate_multiplier(bpg_cs *cs, const uint8_t *left32, const uint8_t *right32, uint64_t out[3]);
 int bpg_cs_constrain(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n);
+
+/* The constraint system as captured so far, one record per linear-combination term in capture order:
+ * vars[t] (packed as above), coeffs32[t] (32 bytes), constraint[t] (index of the constrain() call, counting the two
+ * implicit ones of each multiply()).  *n_terms is always set; BPG_EINVAL if cap is too small.  No counterpart in
+ * bulletproofs (its constraint vector is private): for tests that pin the wiring of a gadget against the
+ * reference's source, and for callers that cache per-circuit data. */
+int bpg_cs_export_terms(const bpg_cs *cs, uint64_t *vars, uint8_t *coeffs32, uint32_t *constraint, size_t cap, size_t *n_terms);
 
 /* The reference's gadget library (same circuits, call for call). */
 int bpg_gadget_binary_constrain(bpg_cs *cs, uint64_t bit_var);                      /* ref: src/gadgets/boolean.rs:12-21 */

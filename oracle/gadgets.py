@@ -135,15 +135,16 @@ class SonnyEdwardsPointGadget:
         cs.constrain(right - left)
 
     def conditionally_select(self, bit, cs):
-        """ref: edwards_point.rs:215-253"""
+        """ref: edwards_point.rs:215-253.  The `let (bit, _, ..)` bindings at :227 and :237 live inside the
+        y' / z' blocks only: the multiplies at :237 and :246 use the right wire of the first multiply (:221)."""
         one = LC.of(1)
         _, bit, x_prime = cs.multiply(self.X.clone(), bit)
-        bit, _, bit_t_y = cs.multiply(LC.of(bit), self.Y.clone())
-        y_prime = bit_t_y + one.clone() - bit
-        cs.constrain(y_prime.clone() - bit_t_y - one.clone() + bit)
-        bit, _, bit_t_z = cs.multiply(LC.of(bit), self.Z.clone())
-        z_prime = bit_t_z + one.clone() - bit
-        cs.constrain(z_prime.clone() - bit_t_z - one + bit)
+        bit_y, _, bit_t_y = cs.multiply(LC.of(bit), self.Y.clone())
+        y_prime = bit_t_y + one.clone() - bit_y
+        cs.constrain(y_prime.clone() - bit_t_y - one.clone() + bit_y)
+        bit_z, _, bit_t_z = cs.multiply(LC.of(bit), self.Z.clone())
+        z_prime = bit_t_z + one.clone() - bit_z
+        cs.constrain(z_prime.clone() - bit_t_z - one + bit_z)
         _, _, t_prime = cs.multiply(self.T.clone(), LC.of(bit))
         return type(self)(x_prime, y_prime, z_prime, t_prime)
 

@@ -156,3 +156,90 @@ def test_termvec_under_sanitizers(tmp_path):
                     "-Xarch_host", "-fno-omit-frame-pointer", "-I" + os.path.join(root, "include"), src, "-o", exe], check=True, cwd=root)
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "termvec: ok" in r.stdout, r.stdout + r.stderr
+
+
+def _cond_select_terms_from_the_rust(X, Y, Z, T):
+    """The (kind, index, coeff, constraint) list that reference/src/gadgets/point/edwards_point.rs:215-253
+    (ristretto_point.rs:184-226 is the same text) produces for `point.conditionally_select(bit, cs)` with a
+    constant point and bit = Variable::Committed(0), derived by hand from the Rust, multiply by multiply:
+      :221  (_, bit, x')      = multiply(X, bit)            multiplier 0; `bit` := MultiplierRight(0)
+      :227  (bit_y, _, bit*y) = multiply(bit, Y)            multiplier 1; bit_y shadows `bit` inside the block only
+      :229  constrain(y' - bit*y - 1 + bit_y),  y' = bit*y + 1 - bit_y
+      :237  (bit_z, _, bit*z) = multiply(bit, Z)            multiplier 2; left input is MultiplierRight(0) again
+      :239  constrain(z' - bit*z - 1 + bit_z)
+      :246  (_, _, t')        = multiply(T, bit)            multiplier 3; right input is MultiplierRight(0)
+    Each multiply(l, r) appends two constraints: l - MultiplierLeft(i) and r - MultiplierRight(i)."""
+    C, Lf, R, O, ONE = 0, 1, 2, 3, 4
+    m1 = g.L - 1
+    return [
+        (ONE, 0, X, 0), (Lf, 0, m1, 0),          # X - L0
+        (C, 0, 1, 1), (R, 0, m1, 1),             # bit - R0
+        (R, 0, 1, 2), (Lf, 1, m1, 2),            # R0 - L1
+        (ONE, 0, Y, 3), (R, 1, m1, 3),           # Y - R1
+        (O, 1, 1, 4), (ONE, 0, 1, 4), (Lf, 1, m1, 4), (O, 1, m1, 4), (ONE, 0, m1, 4), (Lf, 1, 1, 4),
+        (R, 0, 1, 5), (Lf, 2, m1, 5),            # R0 - L2   (not L1: the inner `bit` went out of scope at :231)
+        (ONE, 0, Z, 6), (R, 2, m1, 6),           # Z - R2
+        (O, 2, 1, 7), (ONE, 0, 1, 7), (Lf, 2, m1, 7), (O, 2, m1, 7), (ONE, 0, m1, 7), (Lf, 2, 1, 7),
+        (ONE, 0, T, 8), (Lf, 3, m1, 8),          # T - L3
+        (R, 0, 1, 9), (R, 3, m1, 9),             # R0 - R3   (not L2)
+    ]
+
+
+def test_conditionally_select_wiring_matches_the_rust(oracle):
+    """block-scoped shadowing of `bit` -- the wiring of every circuit that uses conditionally_select,
+    scalar_mul or sk_knowledge.  Product (both gadget types) and oracle against the hand-derived list."""
+    from oracle import gadgets as OG
+    from tests.backends import OracleBackend
+    rnd = random.Random(11)
+    p = sonny.random_point(rnd)
+    want = _cond_select_terms_from_the_rust(p.X % g.L, p.Y % g.L, p.Z % g.L, p.T % g.L)
+    for make in (lambda: g.SonnyEdwardsPointGadget.from_point(p),):
+        v = g.Verifier(b"wiring")
+        bit = v.commit(bytes(32))
+        make().conditionally_select(g.LC.of(bit), v)
+        assert v.export_terms() == want
+    # the Ristretto gadget's conditionally_select on the same LCs (ristretto_point.rs:184-226)
+    v = g.Verifier(b"wiring")
+    bit = v.commit(bytes(32))
+    import ctypes
+    from bulletproofs_gadgets_amd._native import lib, check
+    e = g.SonnyEdwardsPointGadget.from_point(p)
+    vv, cc, n = g.LC.of(bit).marshal()
+    h = ctypes.c_void_p()
+    check(lib().bpg_ristretto_conditionally_select(v._cs, e._h, vv, cc, n, ctypes.byref(h)))
+    lib().bpg_point_free(h)
+    assert v.export_terms() == want
+    # the oracle's restatement
+    be = OracleBackend(oracle)
+    ov = be.Verifier(be.Transcript(b"wiring"))
+    obit = ov.commit(bytes(32))
+    OG.SonnyEdwardsPointGadget.from_point(p).conditionally_select(be.lc(obit), ov)
+    kind = {"C": 0, "L": 1, "R": 2, "O": 3, "One": 4}
+    got = [(kind[var.kind], var.i, c % g.L, q) for q, lc in enumerate(ov.constraints) for var, c in lc.terms]
+    assert got == want
+
+
+def test_foreign_variables_are_rejected():
+    """a variable that this constraint system never issued (another prover's, a stale handle, a
+    made-up kind) is BPG_EINVAL at the ABI, not a write past the flattening plan"""
+    from bulletproofs_gadgets_amd import BpgError, _native
+    v = g.Verifier(b"vars")
+    c0 = v.commit(bytes(32))
+    l, r, o = v.multiply(g.LC.of(c0), g.LC.of(1))
+    for bad in (g.Variable((0 << 32) | 1),          # Committed(1): only one commitment exists
+                g.Variable((1 << 32) | 1),          # MultiplierLeft(1): only multiplier 0 exists
+                g.Variable((3 << 32) | 0x0fffffff),
+                g.Variable((5 << 32) | 0),          # no such kind
+                g.Variable((4 << 32) | 7)):         # One carries no index
+        for call in (lambda: v.constrain(g.LC.of(bad)), lambda: v.multiply(g.LC.of(bad), g.LC.of(1)),
+                     lambda: v.multiply(g.LC.of(c0), g.LC.of(bad)), lambda: g.binary_constrain_gadget(v, bad)):
+            with pytest.raises(BpgError) as e:
+                call()
+            assert e.value.code == _native.EINVAL
+    # a gadget assembled from foreign variables is caught when it reaches the constraint system
+    gp = g.SonnyEdwardsPointGadget.from_vars([g.Variable((1 << 32) | 9)] * 4)
+    with pytest.raises(BpgError) as e:
+        gp.double(v)
+    assert e.value.code == _native.EINVAL
+    assert v.stats()[0] >= 1        # the system is still usable for well-formed input
+    v.constrain(g.LC.of(o) - g.LC.of(l))
