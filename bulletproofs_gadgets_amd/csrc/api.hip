@@ -25,8 +25,11 @@ __device__ __forceinline__ void store_aniels(aniels_rec *rec, const ge_aniels &q
     p[3] = make_uint4(q.YmX.v[4], q.YmX.v[5], q.YmX.v[6], q.YmX.v[7]);
     p[4] = make_uint4(q.T2d.v[0], q.T2d.v[1], q.T2d.v[2], q.T2d.v[3]);
     p[5] = make_uint4(q.T2d.v[4], q.T2d.v[5], q.T2d.v[6], q.T2d.v[7]);
-    p[6] = make_uint4(0, 0, 0, 0);
-    p[7] = make_uint4(0, 0, 0, 0);
+    // fourth slot: -2dxy, so that the record of -P is this record read in another order (msm.hip: load_aniels_signed)
+    fe nt;
+    fe_neg(nt, q.T2d);
+    p[6] = make_uint4(nt.v[0], nt.v[1], nt.v[2], nt.v[3]);
+    p[7] = make_uint4(nt.v[4], nt.v[5], nt.v[6], nt.v[7]);
 }
 
 // CompressedRistretto::decompress per thread; invalid encodings raise *bad and store the identity

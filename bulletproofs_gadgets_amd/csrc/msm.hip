@@ -29,6 +29,7 @@
 #include <cstring>
 
 #include "bpg_internal.h"
+#include "hot25519.h"
 
 namespace bpg {
 
@@ -714,15 +715,32 @@ __device__ __forceinline__ const aniels_rec *record_of(const seg_map &m, uint32_
     return (const aniels_rec *)b0 + i;
 }
 
-// THE hot kernel.  Thread t owns segment `rank` (S0 entries) of bucket g = map0[t] and sums
-// it with 7M mixed additions.  VALU-issue bound: ~1300 integer instructions per addition,
-// 504 of them v_mad_u64_u32.
+// The table entry as the digit's sign selects it: a record is (y+x | y-x | 2dxy | -2dxy), 32 bytes each, so the
+// entry of -P is the same record read in another order -- three addresses instead of 48 v_cndmask_b32.
+__device__ __forceinline__ void load_aniels_signed(ge_aniels_signed &q, const aniels_rec *rec, uint32_t neg) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(rec);
+    const uint4 *pa = p + 2 * neg, *pb = p + 2 - 2 * neg, *pc = p + 4 + 2 * neg;
+    uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1], c0 = pc[0], c1 = pc[1];
+    q.A.v[0] = a0.x; q.A.v[1] = a0.y; q.A.v[2] = a0.z; q.A.v[3] = a0.w;
+    q.A.v[4] = a1.x; q.A.v[5] = a1.y; q.A.v[6] = a1.z; q.A.v[7] = a1.w;
+    q.B.v[0] = b0.x; q.B.v[1] = b0.y; q.B.v[2] = b0.z; q.B.v[3] = b0.w;
+    q.B.v[4] = b1.x; q.B.v[5] = b1.y; q.B.v[6] = b1.z; q.B.v[7] = b1.w;
+    q.C.v[0] = c0.x; q.C.v[1] = c0.y; q.C.v[2] = c0.z; q.C.v[3] = c0.w;
+    q.C.v[4] = c1.x; q.C.v[5] = c1.y; q.C.v[6] = c1.z; q.C.v[7] = c1.w;
+}
+
+// THE hot kernel.  Thread t owns segment `rank` (about S0 entries) of bucket g = map0[t] and sums it with mixed
+// additions (7M each), the generated instruction stream of madd_gfx950.inc: VALU-issue bound, 504 v_mad_u64_u32
+// and ~660 other VALU instructions per addition, four waves per SIMD (128 VGPRs: 32 accumulator, 24 table entry,
+// 56 scratch of the stream).  The first entry of a segment costs one multiplication, not seven: identity + P = P.
+// No LDS staging: every lane adds a different table entry into a different partial sum, so there is nothing for
+// the lanes of a workgroup to share; the entries of a bucket are contiguous and the table is gathered by 128-byte
+// records, one cache line each.
 template <bool MULTI>
-__global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__ entries,
-                                                    const uint32_t *__restrict__ counts,
-                                                    const uint32_t *__restrict__ ent_off, level_ref lv0,
-                                                    const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts,
-                                                    uint32_t nblk, int ls0, seg_map map, uint32_t wstride) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ent_off,
+             level_ref lv0, const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts, uint32_t nblk, int ls0, seg_map map,
+             uint32_t wstride) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= lv0.base[nblk]) return;
     const uint32_t g = map0[t];
@@ -735,17 +753,39 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint32_t *__restrict__
     const uint32_t base = cnt / k, rem = cnt - base * k;
     const uint32_t lo = rank * base + (rank < rem ? rank : rem);
     const uint32_t hi = lo + base + (rank < rem ? 1u : 0u);
-    ge acc;
-    ge_identity(acc);
-    for (uint32_t e = off + lo; e < off + hi; e++) {
-        uint32_t en = entries[e];
-        ge_aniels q;
-        // variable-base: wstride = 0 and the entry is index | sign; fixed-base: window w's copy
-        // of point i (2^(c w) P_i) lives wstride records further per window
+    // variable-base: wstride = 0 and the entry is index | sign; fixed-base: window w's copy of point i
+    // (2^(c w) P_i) lives wstride records further per window (<= 28 windows)
+    auto record = [&](uint32_t en) {
         const uint32_t idx = wstride ? (en & 0x03ffffffu) : (en & 0x7fffffffu);
-        const uint32_t win = wstride ? ((en >> 26) & 31u) : 0u;   // fixed-base tables have <= 28 windows
-        load_aniels(q, record_of<MULTI>(map, idx) + (size_t)win * wstride);
-        ge_madd(acc, acc, q, (en >> 31) != 0);
+        const uint32_t win = wstride ? ((en >> 26) & 31u) : 0u;
+        return record_of<MULTI>(map, idx) + (size_t)win * wstride;
+    };
+    ge acc;
+    uint32_t e = off + lo;
+    const uint32_t eend = off + hi;
+    if (e >= eend) {                                       // (cannot happen: a thread exists for >= 1 entry)
+        ge_identity(acc);
+        store_ge(parts + t, acc);
+        return;
+    }
+    uint32_t en = entries[e];
+    {
+        // identity + P = P as (4x : 4y : 4 : 4xy): A - B = +-2x, A + B = 2y
+        ge_aniels_signed q;
+        load_aniels_signed(q, record(en), en >> 31);
+        fe ex, hy;
+        fe_sub(ex, q.A, q.B);
+        fe_add(hy, q.A, q.B);
+        fe_add(acc.X, ex, ex);
+        fe_add(acc.Y, hy, hy);
+        fe_setu32(acc.Z, 4);
+        fe_mul(acc.T, ex, hy);
+    }
+    for (e++; e < eend; e++) {
+        en = entries[e];
+        ge_aniels_signed q;
+        load_aniels_signed(q, record(en), en >> 31);
+        gez_madd_asm(acc, q);
     }
     store_ge(parts + t, acc);
 }
@@ -1017,8 +1057,10 @@ __global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ 
     o[3] = make_uint4(r.YmX.v[4], r.YmX.v[5], r.YmX.v[6], r.YmX.v[7]);
     o[4] = make_uint4(r.T2d.v[0], r.T2d.v[1], r.T2d.v[2], r.T2d.v[3]);
     o[5] = make_uint4(r.T2d.v[4], r.T2d.v[5], r.T2d.v[6], r.T2d.v[7]);
-    o[6] = make_uint4(0, 0, 0, 0);
-    o[7] = make_uint4(0, 0, 0, 0);
+    fe nt;
+    fe_neg(nt, r.T2d);
+    o[6] = make_uint4(nt.v[0], nt.v[1], nt.v[2], nt.v[3]);
+    o[7] = make_uint4(nt.v[4], nt.v[5], nt.v[6], nt.v[7]);
 }
 
 // ------------------------------------------------------------------ host side

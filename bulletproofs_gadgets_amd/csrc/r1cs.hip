@@ -404,8 +404,11 @@ __global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict_
         dst[t] = o.YpX.v[t];
         dst[8 + t] = o.YmX.v[t];
         dst[16 + t] = o.T2d.v[t];
-        dst[24 + t] = 0;
     }
+    fe nt;
+    fe_neg(nt, o.T2d);
+#pragma unroll
+    for (int t = 0; t < 8; t++) dst[24 + t] = nt.v[t];
 }
 
 // =================================================================== host: store / sonny / proof bytes

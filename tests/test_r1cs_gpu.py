@@ -409,32 +409,46 @@ def test_allocation_failure_releases_jobs_and_workspaces(gpu_ctx, rnd):
     import bulletproofs_gadgets_amd as bpg
     from bulletproofs_gadgets_amd import _native, synth
     lib = _native.lib()
-    n = 3000
-    pts = gpu_ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"af"))
-    sc = synth.scalars(n, tag=b"af-s")
-    want = gpu_ctx.msm(pts, sc)
-    # a larger MSM than any before on this lane: every workspace of the job has to grow, so each of the first
-    # few allocations can be made to fail in turn
-    n2 = 40000
-    pts2 = gpu_ctx.points_from_uniform(synth.uniform_bytes(n2, tag=b"af2"))
-    sc2 = synth.scalars(n2, tag=b"af2-s")
-    # countdown 2: the first workspace still to grow grows, the next allocation fails -- repeated, this walks
-    # through every allocation site of the submit path, one per attempt, until nothing is left to grow
-    failures = 0
-    for _ in range(24):
-        lib.bpg_debug_fail_alloc(2 if failures else 1)
-        try:
-            gpu_ctx.msm(pts2, sc2)
-            break
-        except bpg.BpgError as e:
-            assert e.code in (_native.EDEVICE, _native.ENOMEM)
-            failures += 1
-        finally:
-            lib.bpg_debug_fail_alloc(0)
-        assert gpu_ctx.msm(pts, sc) == want          # the lane's job pool still works after every failure ...
-    assert failures >= 4
-    big = gpu_ctx.msm(pts2, sc2)                     # ... and the call that failed now succeeds
-    assert big == gpu_ctx.msm(pts2, sc2)
+    ctx = bpg.Context(0)          # a fresh context: its lanes and MSM jobs have no workspace yet, everything has to grow
+    try:
+        n = 3000
+        pts = ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"af"))
+        sc = synth.scalars(n, tag=b"af-s")
+        want = gpu_ctx.msm(gpu_ctx.points_from_uniform(synth.uniform_bytes(n, tag=b"af")), sc)
+        # countdown 2: the first workspace still to grow grows, the next allocation fails -- repeated, this walks
+        # through every allocation site of the submit path, one per attempt, until nothing is left to grow
+        failures = 0
+        for _ in range(24):
+            lib.bpg_debug_fail_alloc(2 if failures else 1)
+            try:
+                got = ctx.msm(pts, sc)
+                break
+            except bpg.BpgError as e:
+                assert e.code in (_native.EDEVICE, _native.ENOMEM)
+                failures += 1
+            finally:
+                lib.bpg_debug_fail_alloc(0)
+        assert failures >= 4 and got == want
+        # a larger MSM afterwards: the buffers grow again, through the same failures, and the small one still works between them
+        n2 = 40000
+        pts2 = ctx.points_from_uniform(synth.uniform_bytes(n2, tag=b"af2"))
+        sc2 = synth.scalars(n2, tag=b"af2-s")
+        failures = 0
+        for _ in range(24):
+            lib.bpg_debug_fail_alloc(2 if failures else 1)
+            try:
+                big = ctx.msm(pts2, sc2)
+                break
+            except bpg.BpgError as e:
+                assert e.code in (_native.EDEVICE, _native.ENOMEM)
+                failures += 1
+            finally:
+                lib.bpg_debug_fail_alloc(0)
+            assert ctx.msm(pts, sc) == want          # the lane's job pool still works after every failure
+        assert failures >= 3
+        assert big == ctx.msm(pts2, sc2) == gpu_ctx.msm(gpu_ctx.points_from_uniform(synth.uniform_bytes(n2, tag=b"af2")), sc2)
+    finally:
+        ctx.close()
     # prove / verify: the failure surfaces as an error code and the next proof is byte-identical to a clean one
     gbe = GpuBackend(gpu_ctx)
     a, b = sonny.random_point(rnd), sonny.random_point(rnd)
