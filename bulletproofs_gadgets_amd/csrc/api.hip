@@ -19,15 +19,15 @@ void set_last_error_msg(const char *what) { snprintf(g_err, sizeof g_err, "%s", 
 
 __device__ __forceinline__ void store_aniels(aniels_rec *rec, const ge_aniels &q) {
     uint4 *p = reinterpret_cast<uint4 *>(rec);
-    p[0] = make_uint4(q.YpX.v[0], q.YpX.v[1], q.YpX.v[2], q.YpX.v[3]);
-    p[1] = make_uint4(q.YpX.v[4], q.YpX.v[5], q.YpX.v[6], q.YpX.v[7]);
-    p[2] = make_uint4(q.YmX.v[0], q.YmX.v[1], q.YmX.v[2], q.YmX.v[3]);
-    p[3] = make_uint4(q.YmX.v[4], q.YmX.v[5], q.YmX.v[6], q.YmX.v[7]);
-    p[4] = make_uint4(q.T2d.v[0], q.T2d.v[1], q.T2d.v[2], q.T2d.v[3]);
-    p[5] = make_uint4(q.T2d.v[4], q.T2d.v[5], q.T2d.v[6], q.T2d.v[7]);
+    p[0] = make_uint4(q.hYpX.v[0], q.hYpX.v[1], q.hYpX.v[2], q.hYpX.v[3]);
+    p[1] = make_uint4(q.hYpX.v[4], q.hYpX.v[5], q.hYpX.v[6], q.hYpX.v[7]);
+    p[2] = make_uint4(q.hYmX.v[0], q.hYmX.v[1], q.hYmX.v[2], q.hYmX.v[3]);
+    p[3] = make_uint4(q.hYmX.v[4], q.hYmX.v[5], q.hYmX.v[6], q.hYmX.v[7]);
+    p[4] = make_uint4(q.Tdxy.v[0], q.Tdxy.v[1], q.Tdxy.v[2], q.Tdxy.v[3]);
+    p[5] = make_uint4(q.Tdxy.v[4], q.Tdxy.v[5], q.Tdxy.v[6], q.Tdxy.v[7]);
     // fourth slot: -2dxy, so that the record of -P is this record read in another order (msm.hip: load_aniels_signed)
     fe nt;
-    fe_neg(nt, q.T2d);
+    fe_neg(nt, q.Tdxy);
     p[6] = make_uint4(nt.v[0], nt.v[1], nt.v[2], nt.v[3]);
     p[7] = make_uint4(nt.v[4], nt.v[5], nt.v[6], nt.v[7]);
 }
@@ -73,24 +73,14 @@ __global__ void __launch_bounds__(256) k_compress(const aniels_rec *__restrict__
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t *w = table[i].w;
-    fe yp, ym, inv2, x, y;
+    ge_aniels q;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        yp.v[k] = w[k];
-        ym.v[k] = w[8 + k];
-        inv2.v[k] = 0xffffffffu;
+        q.hYpX.v[k] = w[k];
+        q.hYmX.v[k] = w[8 + k];
     }
-    inv2.v[0] = 0xfffffff7u;
-    inv2.v[7] = 0x3fffffffu;          // (p+1)/2
-    fe_sub(x, yp, ym);
-    fe_add(y, yp, ym);
-    fe_mul(x, x, inv2);
-    fe_mul(y, y, inv2);
     ge P;
-    P.X = x;
-    P.Y = y;
-    fe_set1(P.Z);
-    fe_mul(P.T, x, y);
+    ge_from_aniels(P, q);
     uint32_t b[8];
     ristretto_encode_w(b, P);
     uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * i);
@@ -203,19 +193,10 @@ __global__ void __launch_bounds__(256) k_shift_table(aniels_rec *__restrict__ ta
     {
         const uint4 *q = reinterpret_cast<const uint4 *>(table + i);
         uint4 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3];
-        fe ypx = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}}, ymx = {{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}};
-        fe two_y, two_x;
-        fe_add(two_y, ypx, ymx);
-        fe_sub(two_x, ypx, ymx);
-        // projective (2x : 2y : 2) is the same point; T = (2x)(2y)/2 = 2xy
-        p.X = two_x;
-        p.Y = two_y;
-        fe_setu32(p.Z, 2);
-        fe xy;
-        fe_mul(xy, two_x, two_y);
-        // T = XY/Z = (2x)(2y)/2: multiply by 1/2 = (p+1)/2
-        fe h = {{0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu}};
-        fe_mul(p.T, xy, h);
+        ge_aniels q0;
+        q0.hYpX = {{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}};
+        q0.hYmX = {{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}};
+        ge_from_aniels(p, q0);
     }
     fe prod;
     fe_set1(prod);

@@ -16,7 +16,7 @@ namespace bpg {
 
 // One resident table entry: affine Niels point, one 128-B line.
 struct alignas(16) aniels_rec {
-    uint32_t w[32];   // [0..8) y+x, [8..16) y-x, [16..24) 2dxy, [24..32) -2dxy (the entry of -P is the same record re-read)
+    uint32_t w[32];   // [0..8) (y+x)/2, [8..16) (y-x)/2, [16..24) dxy, [24..32) -dxy (the entry of -P is the same record re-read)
 };
 static_assert(sizeof(aniels_rec) == 128, "table stride is one cache line");
 

@@ -16,8 +16,9 @@
 //    to limb 0 overflows it with probability < 2^-21) sit behind a branch on the carry mask
 //    instead of eight v_addc_co_u32 on every call.
 //  * A signed Pippenger digit negates the table point.  The table record holds
-//    (y+x, y-x, 2dxy, -2dxy), so the negated point is the same record read in another order:
-//    an address choice instead of 48 v_cndmask_b32 per addition.
+//    ((y+x)/2, (y-x)/2, dxy, -dxy), so the negated point is the same record read in another order:
+//    an address choice instead of 48 v_cndmask_b32 per addition.  (Halved: see ge25519.h -- the
+//    addition then uses Z where the usual form uses 2Z.)
 //
 // Replaces, for Prover::prove / Verifier::verify's multiscalar multiplications, what
 // curve25519-dalek's FieldElement / EdwardsPoint do under Straus / Pippenger
@@ -156,25 +157,24 @@ __device__ __forceinline__ void fez_mul(fe &r, const fe &a, const fe &b, const f
     fez_reduce512(r, acc, Z);
 }
 
-// The three field elements of a table record as a mixed addition consumes them: for a negative
-// digit (y-x, y+x, -2dxy), i.e. the record of -P.
+// The three field elements of a table record as a mixed addition consumes them: ((y+x)/2, (y-x)/2, dxy) of +P, or
+// for a negative digit ((y-x)/2, (y+x)/2, -dxy), i.e. the record of -P.
 struct ge_aniels_signed {
-    fe A, B, C;          // multiplies (Y+X), (Y-X), T
+    fe A, B, C;          // multiply (Y+X), (Y-X), T
 };
 
-// r = p + q, q as read by the sign; 7M, 8 add/sub, no selects
+// r = p + q, q as read by the sign; 7M, 7 add/sub, no selects
 __device__ __forceinline__ void gez_madd(ge &r, const ge &p, const ge_aniels_signed &q, const fe_zeros &Z) {
-    fe a, b, c, d, e, f, g, h, t;
+    fe a, b, c, e, f, g, h, t;
     fez_sub(t, p.Y, p.X);
     fez_add(h, p.Y, p.X);
     fez_mul(a, t, q.B, Z);
     fez_mul(b, h, q.A, Z);
     fez_mul(c, p.T, q.C, Z);
-    fez_add(d, p.Z, p.Z);
     fez_sub(e, b, a);
     fez_add(h, b, a);
-    fez_sub(f, d, c);
-    fez_add(g, d, c);
+    fez_sub(f, p.Z, c);
+    fez_add(g, p.Z, c);
     fez_mul(r.X, e, f, Z);
     fez_mul(r.Y, g, h, Z);
     fez_mul(r.T, e, h, Z);
@@ -185,16 +185,12 @@ __device__ __forceinline__ void gez_madd(ge &r, const ge &p, const ge_aniels_sig
 // pairs, three carry chains in flight, no s_nop, no spills.  p += q; q is overwritten.
 #include "madd_gfx950.inc"
 
-// r = identity + q = q, as the extended point (4x : 4y : 4 : 4xy): one multiplication instead of seven.
-// (A - B = +-2x, A + B = 2y; X Y = T Z holds: 4x 4y = 4xy 4.)
-__device__ __forceinline__ void gez_from_aniels(ge &r, const ge_aniels_signed &q, const fe_zeros &Z) {
-    fe e, h;
-    fez_sub(e, q.A, q.B);
-    fez_add(h, q.A, q.B);
-    fez_add(r.X, e, e);
-    fez_add(r.Y, h, h);
-    fe_setu32(r.Z, 4);
-    fez_mul(r.T, e, h, Z);
+// r = identity + q = q: x = A - B, y = A + B, Z = 1, T = xy -- one multiplication instead of seven
+__device__ __forceinline__ void gez_from_aniels(ge &r, const ge_aniels_signed &q) {
+    fe_sub(r.X, q.A, q.B);
+    fe_add(r.Y, q.A, q.B);
+    fe_set1(r.Z);
+    fe_mul(r.T, r.X, r.Y);
 }
 
 // r = p + q (both extended), 9M

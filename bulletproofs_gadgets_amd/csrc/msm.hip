@@ -40,12 +40,12 @@ constexpr int MAX_LEVELS = 8;     // accumulate pass + up to 7 merge passes
 __device__ __forceinline__ void load_aniels(ge_aniels &q, const aniels_rec *rec) {
     const uint4 *p = reinterpret_cast<const uint4 *>(rec);
     uint4 a0 = p[0], a1 = p[1], b0 = p[2], b1 = p[3], c0 = p[4], c1 = p[5];
-    q.YpX.v[0] = a0.x; q.YpX.v[1] = a0.y; q.YpX.v[2] = a0.z; q.YpX.v[3] = a0.w;
-    q.YpX.v[4] = a1.x; q.YpX.v[5] = a1.y; q.YpX.v[6] = a1.z; q.YpX.v[7] = a1.w;
-    q.YmX.v[0] = b0.x; q.YmX.v[1] = b0.y; q.YmX.v[2] = b0.z; q.YmX.v[3] = b0.w;
-    q.YmX.v[4] = b1.x; q.YmX.v[5] = b1.y; q.YmX.v[6] = b1.z; q.YmX.v[7] = b1.w;
-    q.T2d.v[0] = c0.x; q.T2d.v[1] = c0.y; q.T2d.v[2] = c0.z; q.T2d.v[3] = c0.w;
-    q.T2d.v[4] = c1.x; q.T2d.v[5] = c1.y; q.T2d.v[6] = c1.z; q.T2d.v[7] = c1.w;
+    q.hYpX.v[0] = a0.x; q.hYpX.v[1] = a0.y; q.hYpX.v[2] = a0.z; q.hYpX.v[3] = a0.w;
+    q.hYpX.v[4] = a1.x; q.hYpX.v[5] = a1.y; q.hYpX.v[6] = a1.z; q.hYpX.v[7] = a1.w;
+    q.hYmX.v[0] = b0.x; q.hYmX.v[1] = b0.y; q.hYmX.v[2] = b0.z; q.hYmX.v[3] = b0.w;
+    q.hYmX.v[4] = b1.x; q.hYmX.v[5] = b1.y; q.hYmX.v[6] = b1.z; q.hYmX.v[7] = b1.w;
+    q.Tdxy.v[0] = c0.x; q.Tdxy.v[1] = c0.y; q.Tdxy.v[2] = c0.z; q.Tdxy.v[3] = c0.w;
+    q.Tdxy.v[4] = c1.x; q.Tdxy.v[5] = c1.y; q.Tdxy.v[6] = c1.z; q.Tdxy.v[7] = c1.w;
 }
 
 __device__ __forceinline__ void load_ge(ge &r, const ge_rec *rec) {
@@ -715,7 +715,7 @@ __device__ __forceinline__ const aniels_rec *record_of(const seg_map &m, uint32_
     return (const aniels_rec *)b0 + i;
 }
 
-// The table entry as the digit's sign selects it: a record is (y+x | y-x | 2dxy | -2dxy), 32 bytes each, so the
+// The table entry as the digit's sign selects it: a record is ((y+x)/2 | (y-x)/2 | dxy | -dxy), 32 bytes each, so the
 // entry of -P is the same record read in another order -- three addresses instead of 48 v_cndmask_b32.
 __device__ __forceinline__ void load_aniels_signed(ge_aniels_signed &q, const aniels_rec *rec, uint32_t neg) {
     const uint4 *p = reinterpret_cast<const uint4 *>(rec);
@@ -770,16 +770,9 @@ k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ 
     }
     uint32_t en = entries[e];
     {
-        // identity + P = P as (4x : 4y : 4 : 4xy): A - B = +-2x, A + B = 2y
-        ge_aniels_signed q;
+        ge_aniels_signed q;                                // identity + P = P
         load_aniels_signed(q, record(en), en >> 31);
-        fe ex, hy;
-        fe_sub(ex, q.A, q.B);
-        fe_add(hy, q.A, q.B);
-        fe_add(acc.X, ex, ex);
-        fe_add(acc.Y, hy, hy);
-        fe_setu32(acc.Z, 4);
-        fe_mul(acc.T, ex, hy);
+        gez_from_aniels(acc, q);
     }
     for (e++; e < eend; e++) {
         en = entries[e];
@@ -1051,14 +1044,14 @@ __global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ 
     ge_aniels r;
     ge_to_aniels(r, p, zinv);
     uint4 *o = reinterpret_cast<uint4 *>(tab + tg);
-    o[0] = make_uint4(r.YpX.v[0], r.YpX.v[1], r.YpX.v[2], r.YpX.v[3]);
-    o[1] = make_uint4(r.YpX.v[4], r.YpX.v[5], r.YpX.v[6], r.YpX.v[7]);
-    o[2] = make_uint4(r.YmX.v[0], r.YmX.v[1], r.YmX.v[2], r.YmX.v[3]);
-    o[3] = make_uint4(r.YmX.v[4], r.YmX.v[5], r.YmX.v[6], r.YmX.v[7]);
-    o[4] = make_uint4(r.T2d.v[0], r.T2d.v[1], r.T2d.v[2], r.T2d.v[3]);
-    o[5] = make_uint4(r.T2d.v[4], r.T2d.v[5], r.T2d.v[6], r.T2d.v[7]);
+    o[0] = make_uint4(r.hYpX.v[0], r.hYpX.v[1], r.hYpX.v[2], r.hYpX.v[3]);
+    o[1] = make_uint4(r.hYpX.v[4], r.hYpX.v[5], r.hYpX.v[6], r.hYpX.v[7]);
+    o[2] = make_uint4(r.hYmX.v[0], r.hYmX.v[1], r.hYmX.v[2], r.hYmX.v[3]);
+    o[3] = make_uint4(r.hYmX.v[4], r.hYmX.v[5], r.hYmX.v[6], r.hYmX.v[7]);
+    o[4] = make_uint4(r.Tdxy.v[0], r.Tdxy.v[1], r.Tdxy.v[2], r.Tdxy.v[3]);
+    o[5] = make_uint4(r.Tdxy.v[4], r.Tdxy.v[5], r.Tdxy.v[6], r.Tdxy.v[7]);
     fe nt;
-    fe_neg(nt, r.T2d);
+    fe_neg(nt, r.Tdxy);
     o[6] = make_uint4(nt.v[0], nt.v[1], nt.v[2], nt.v[3]);
     o[7] = make_uint4(nt.v[4], nt.v[5], nt.v[6], nt.v[7]);
 }
@@ -1223,32 +1216,178 @@ void msm_job_destroy(bpg_msm_job *j) {
     delete j;
 }
 
+// ---- one Pippenger run: geometry, workspace, and the three groups of launches.  msm_submit() takes the workspace
+//      from a job's growable buffers; msm_noalloc() (further down) from the library's static device array.
+struct msm_geom {
+    size_t NE, M, nblk, lvl_words, map_words, NBT, NCH, part_total;
+    size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS];
+    int nlevels, logchunk, lognch, per0, LOWN;
+    uint32_t CH;
+    // bytes of each workspace buffer
+    size_t b_digits, b_entries, b_counts, b_tmp, b_partials, b_chunk, b_out;
+};
+struct msm_bufs {
+    int16_t *digits;
+    uint32_t *entries, *counts;
+    uint2 *tmp;
+    ge_rec *partials, *chunk, *out;
+};
+struct msm_maps {
+    seg_map map;
+    sc_map smap;
+};
+
+static int msm_geometry(const msm_plan &pl, size_t n, int T, msm_geom &g) {
+    g.NE = (size_t)T * pl.Wb * pl.NB;                      // buckets
+    g.M = (size_t)T * pl.W * n;                            // upper bound on entries
+    if (g.M >= ((size_t)1 << 32) || g.NE >= ((size_t)1 << 30)) return BPG_EINVAL;
+    g.nblk = (g.NE + 1023) / 1024;
+    g.logchunk = ilog2(pl.chunk);
+    g.lognch = ilog2(pl.nchunks);
+    g.per0 = g.logchunk + 1;
+    g.nlevels = pl.R + 1;                                  // levels 0..R
+    if (g.nlevels > MAX_LEVELS) return BPG_EINVAL;
+    // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
+    g.cap_lv[0] = g.M / (size_t)pl.ls0 + g.NE + 1;
+    for (int r = 1; r < g.nlevels; r++) {
+        // a bucket with cnt entries has <= cnt / (S0 S1^r) + 1 threads at level r, and at most half of level r-1
+        const size_t by_count = ((g.M / (size_t)pl.ls0) >> (r * pl.ls1)) + g.NE + 1;
+        g.cap_lv[r] = g.cap_lv[r - 1] / 2 + 1 < by_count ? g.cap_lv[r - 1] / 2 + 1 : by_count;
+    }
+    g.part_total = 0;
+    for (int r = 0; r < g.nlevels; r++) {
+        g.part_off[r] = g.part_total;
+        g.part_total += g.cap_lv[r];
+    }
+    g.lvl_words = g.NE + g.nblk + 1;                       // local[NE] | base[nblk + 1]
+    g.map_words = g.cap_lv[0] + (g.nlevels > 1 ? g.cap_lv[1] : 0);
+    g.NBT = (size_t)T * pl.Wb * pl.nbin;                   // bins
+    g.CH = (uint32_t)pl.sort_chunk;                        // items per level-2 block
+    g.LOWN = pl.NB / pl.nbin;                              // buckets per bin
+    g.NCH = g.M / g.CH + g.NBT;                            // upper bound on chunks: sum of max(1, ceil(cnt / CH))
+    g.b_digits = g.M * sizeof(int16_t);
+    g.b_entries = g.M * sizeof(uint32_t);
+    g.b_counts = (2 * g.NE + (size_t)(g.nlevels + 1) * g.lvl_words + g.map_words + 4 * g.NBT + g.NCH * (size_t)g.LOWN + 16) * sizeof(uint32_t);
+    g.b_tmp = g.M * sizeof(uint2) + 64;                    // level-1 output: (entry, bucket in bin)
+    g.b_partials = g.part_total * sizeof(ge_rec);
+    g.b_chunk = (size_t)T * pl.Wb * pl.nchunks * g.per0 * sizeof(ge_rec);
+    g.b_out = (size_t)T * pl.Wb * pl.outs * sizeof(ge_rec);
+    return BPG_OK;
+}
+
+static int msm_make_maps(const msm_seg *segs, int nseg, size_t n, size_t sc_stride, msm_maps &mm) {
+    size_t acc = 0;
+    for (int k = 0; k < 4; k++) {
+        mm.smap.off[k] = 0;
+        if (k < nseg) {
+            if (segs[k].len && !segs[k].base) return BPG_EINVAL;
+            if (sc_stride && (segs[k].sc_off + segs[k].len > sc_stride || sc_stride >= ((size_t)1 << 32))) return BPG_EINVAL;
+            mm.map.base[k] = segs[k].base - acc;
+            mm.smap.off[k] = (uint32_t)(sc_stride ? segs[k].sc_off : acc);
+            acc += segs[k].len;
+        } else {
+            mm.map.base[k] = nullptr;
+        }
+        mm.map.len[k] = k < nseg ? (uint32_t)acc : 0xffffffffu;
+        mm.smap.end[k] = mm.map.len[k];
+    }
+    if (acc != n) return BPG_EINVAL;
+    mm.smap.stride = sc_stride ? sc_stride : n;
+    return BPG_OK;
+}
+
+// where things live inside the counts buffer
+struct msm_layout {
+    uint32_t *counts, *ent_off, *lvl_base, *map0, *map1, *bin_counts, *bin_fill, *bin_off, *chunk_off, *chunk_hist;
+    levels_dev L;
+};
+static msm_layout msm_lay_out(const msm_geom &g, const msm_bufs &b) {
+    msm_layout y{};
+    y.counts = b.counts;
+    y.ent_off = y.counts + g.NE;
+    y.lvl_base = y.ent_off + g.NE;                         // level -1 (unused), then levels 0..R
+    y.map0 = y.lvl_base + (size_t)(g.nlevels + 1) * g.lvl_words;
+    y.map1 = g.nlevels > 1 ? y.map0 + g.cap_lv[0] : nullptr;
+    y.bin_counts = y.map0 + g.map_words;
+    y.bin_fill = y.bin_counts + g.NBT;
+    y.bin_off = y.bin_fill + g.NBT;
+    y.chunk_off = y.bin_off + g.NBT + 1;
+    y.chunk_hist = y.chunk_off + g.NBT + 1;
+    y.L.nlevels = g.nlevels;
+    for (int r = 0; r < g.nlevels; r++) {
+        y.L.lv[r] = level_ref{y.lvl_base + (size_t)(r + 1) * g.lvl_words, y.lvl_base + (size_t)(r + 1) * g.lvl_words + g.NE};
+        y.L.parts[r] = b.partials + g.part_off[r];
+    }
+    return y;
+}
+
+// digits, two-level bucket sort, thread offsets and thread -> bucket maps of every pass
+static void msm_enqueue_sort(hipStream_t s, const msm_plan &pl, const msm_geom &g, const msm_bufs &b, const msm_layout &y,
+                             const uint32_t *d_sc, size_t n, int T, const sc_map &smap, int shared) {
+    dispatch_digits(pl.c, s, d_sc, b.digits, n, (size_t)T * n, smap, y.bin_counts, (uint32_t)(2 * g.NBT));
+    dim3 tgrid(pl.ntiles, pl.W, T);
+    const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile, shared);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, y.bin_counts, y.bin_off, y.chunk_off, (uint32_t)g.NBT, g.CH);
+    hipLaunchKernelGGL(k_bin_scatter, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_off, y.bin_fill, b.tmp, n, pl.W, pl.nbin,
+                       pl.lowshift, pl.tile, shared);
+    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)g.NCH), dim3(256), 0, s, y.bin_off, y.chunk_off, b.tmp, y.chunk_hist, y.counts,
+                       y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    // (2b and 2c have work only when some bin is larger than a chunk: modest grids that stride)
+    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(g.NBT < 512 ? g.NBT : 512)), dim3(256), 0, s, y.bin_off, y.chunk_off,
+                       y.chunk_hist, y.counts, y.ent_off, (uint32_t)g.NBT, g.LOWN);
+    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(g.NCH < 2048 ? g.NCH : 2048)), dim3(256), 0, s, y.bin_off, y.chunk_off, b.tmp,
+                       y.chunk_hist, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    // thread offsets of every pass (levels 0..R), two launches
+    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)g.nblk), dim3(256), 0, s, y.counts, y.lvl_base, g.lvl_words, g.NE, g.nlevels + 1,
+                       pl.ls0, pl.ls1);
+    hipLaunchKernelGGL(k_scan_b, dim3(g.nlevels + 1), dim3(1024), 0, s, y.lvl_base, g.lvl_words, g.NE, g.nblk);
+    // thread -> bucket maps of levels 0 and 1 (level 1 only exists when nlevels > 1)
+    hipLaunchKernelGGL(k_segmap, dim3((unsigned)((g.NE + 255) / 256)), dim3(256), 0, s, y.counts, y.L.lv[0],
+                       y.L.lv[g.nlevels > 1 ? 1 : 0], y.map0, y.map1, (uint32_t)g.NE, pl.ls0, pl.ls1);
+}
+
+static void msm_enqueue_accumulate(hipStream_t s, const msm_plan &pl, const msm_geom &g, const msm_bufs &b, const msm_layout &y,
+                                   const seg_map &map, bool multi, uint32_t wstride) {
+    const dim3 grid((unsigned)((g.cap_lv[0] + 255) / 256));
+    if (multi)
+        hipLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), 0, s, b.entries, y.counts, y.ent_off, y.L.lv[0], y.map0,
+                           b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
+    else
+        hipLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), 0, s, b.entries, y.counts, y.ent_off, y.L.lv[0], y.map0,
+                           b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
+}
+
+// merge passes and the bit-tree tail: leaves pl.outs points per bucket set in b.out
+static void msm_enqueue_merge_tail(hipStream_t s, const msm_plan &pl, const msm_geom &g, const msm_bufs &b, const msm_layout &y, int T) {
+    const bool wide = pl.ls1 == 4 && g.NE <= 32768;        // latency-bound regime: 4 lanes per merge
+    for (int r = 1; r < g.nlevels; r++) {
+        const uint32_t *mp = r == 1 ? (const uint32_t *)y.map1 : (const uint32_t *)nullptr;
+        if (wide)
+            hipLaunchKernelGGL((k_reduce_wide<4>), dim3((unsigned)((g.cap_lv[r] * 4 + 255) / 256)), dim3(256), 0, s, y.counts,
+                               y.L.lv[r - 1], y.L.lv[r], mp, b.partials + g.part_off[r - 1], b.partials + g.part_off[r],
+                               (uint32_t)g.nblk, (uint32_t)g.NE, r, pl.ls0);
+        else
+            hipLaunchKernelGGL(k_reduce, dim3((unsigned)((g.cap_lv[r] + 255) / 256)), dim3(256), 0, s, y.counts, y.L.lv[r - 1],
+                               y.L.lv[r], mp, b.partials + g.part_off[r - 1], b.partials + g.part_off[r], (uint32_t)g.nblk,
+                               (uint32_t)g.NE, r, pl.ls0, pl.ls1);
+    }
+    ge_rec *a_out = pl.nchunks == 1 ? b.out : b.chunk;
+    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, y.L, y.counts, a_out, pl.NB,
+                       pl.chunk, g.logchunk, pl.Wb, pl.ls0, pl.ls1);
+    if (pl.nchunks > 1)
+        hipLaunchKernelGGL(k_tail_b, dim3(pl.Wb, T), dim3(320), (size_t)pl.nchunks * g.per0 * 128, s, b.chunk, b.out, pl.nchunks,
+                           g.lognch, g.per0, pl.Wb);
+}
+
 int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalars, size_t n, int T, bool scalars_on_host,
                bpg_msm_job **out_job, msm_fixed_base fb, size_t sc_stride) {
     if (!ctx || !segs || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
     if (sc_stride && scalars_on_host) return BPG_EINVAL;
     if (n >= ((size_t)1 << 28) || (fb.c && (n >= ((size_t)1 << 26) || fb.wstride >= ((size_t)1 << 32)))) return BPG_EINVAL;
-    seg_map map{};
-    sc_map smap{};
-    {
-        size_t acc = 0;
-        for (int k = 0; k < 4; k++) {
-            smap.off[k] = 0;
-            if (k < nseg) {
-                if (segs[k].len && !segs[k].base) return BPG_EINVAL;
-                if (sc_stride && (segs[k].sc_off + segs[k].len > sc_stride || sc_stride >= ((size_t)1 << 32))) return BPG_EINVAL;
-                map.base[k] = segs[k].base - acc;
-                smap.off[k] = (uint32_t)(sc_stride ? segs[k].sc_off : acc);
-                acc += segs[k].len;
-            } else {
-                map.base[k] = nullptr;
-            }
-            map.len[k] = k < nseg ? (uint32_t)acc : 0xffffffffu;
-            smap.end[k] = map.len[k];
-        }
-        if (acc != n) return BPG_EINVAL;
-        smap.stride = sc_stride ? sc_stride : n;
-    }
+    msm_maps mm{};
+    int rc;
+    if ((rc = msm_make_maps(segs, nseg, n, sc_stride, mm))) return rc;
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     bpg_msm_job *j = acquire_job(lane);
@@ -1265,21 +1404,14 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     } release{j};
     msm_plan pl = make_plan(n, T, ctx->tune, fb.c, fb.density, ctx->resident_lanes);
     j->plan = pl;
-    const size_t NE = (size_t)T * pl.Wb * pl.NB;          // buckets
-    const size_t M = (size_t)T * pl.W * n;                // upper bound on entries
-    if (M >= ((size_t)1 << 32) || NE >= ((size_t)1 << 30)) return BPG_EINVAL;
-    const size_t nblk = (NE + 1023) / 1024;
-    const int logchunk = ilog2(pl.chunk), lognch = ilog2(pl.nchunks), per0 = logchunk + 1;
-    const int nlevels = pl.R + 1;                          // levels 0..R
-    if (nlevels > MAX_LEVELS) return BPG_EINVAL;
-    int rc;
-    const size_t out_bytes = (size_t)T * pl.Wb * pl.outs * sizeof(ge_rec);
-    if ((rc = grow((void **)&j->d_out, &j->cap_out, out_bytes))) return rc;
-    if (out_bytes > j->cap_hout) {
+    msm_geom g{};
+    if ((rc = msm_geometry(pl, n, T, g))) return rc;
+    if ((rc = grow((void **)&j->d_out, &j->cap_out, g.b_out))) return rc;
+    if (g.b_out > j->cap_hout) {
         if (j->h_out) (void)hipHostFree(j->h_out);
         j->h_out = nullptr;
         j->cap_hout = 0;
-        size_t want = out_bytes * 2;
+        size_t want = g.b_out * 2;
         BPG_CHECK_HIP(hipHostMalloc((void **)&j->h_out, want, hipHostMallocDefault));
         j->cap_hout = want;
     }
@@ -1293,109 +1425,31 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         *out_job = j;
         return BPG_OK;
     }
-    // partial-sum capacity per level: level 0 <= M/S0 + NE, each further level at most half
-    size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS], part_total = 0;
-    cap_lv[0] = M / (size_t)pl.ls0 + NE + 1;
-    for (int r = 1; r < nlevels; r++) {
-        // a bucket with cnt entries has <= cnt / (S0 S1^r) + 1 threads at level r, and at most half of level r-1
-        const size_t by_count = ((M / (size_t)pl.ls0) >> (r * pl.ls1)) + NE + 1;
-        cap_lv[r] = cap_lv[r - 1] / 2 + 1 < by_count ? cap_lv[r - 1] / 2 + 1 : by_count;
-    }
-    for (int r = 0; r < nlevels; r++) {
-        part_off[r] = part_total;
-        part_total += cap_lv[r];
-    }
-    const size_t lvl_words = NE + nblk + 1;                // local[NE] | base[nblk + 1]
-    if ((rc = grow((void **)&j->d_digits, &j->cap_digits, M * sizeof(int16_t)))) return rc;
-    if ((rc = grow((void **)&j->d_entries, &j->cap_entries, M * sizeof(uint32_t)))) return rc;
-    const size_t map_words = cap_lv[0] + (nlevels > 1 ? cap_lv[1] : 0);
-    const size_t NBT = (size_t)T * pl.Wb * pl.nbin;        // bins
-    const uint32_t CH = (uint32_t)pl.sort_chunk;          // items per level-2 block
-    const int LOWN = pl.NB / pl.nbin;                      // buckets per bin
-    const size_t NCH = M / CH + NBT;                       // upper bound on chunks: sum of max(1, ceil(cnt / CH))
-    if ((rc = grow((void **)&j->d_counts, &j->cap_counts,
-                   (2 * NE + (size_t)(nlevels + 1) * lvl_words + map_words + 4 * NBT + NCH * (size_t)LOWN + 16) * sizeof(uint32_t))))
-        return rc;
-    if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, M * sizeof(uint2) + 64))) return rc;    // level-1 output: (entry, bucket in bin)
-    if ((rc = grow((void **)&j->d_partials, &j->cap_partials, part_total * sizeof(ge_rec)))) return rc;
-    if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, (size_t)T * pl.Wb * pl.nchunks * per0 * sizeof(ge_rec)))) return rc;
+    if ((rc = grow((void **)&j->d_digits, &j->cap_digits, g.b_digits))) return rc;
+    if ((rc = grow((void **)&j->d_entries, &j->cap_entries, g.b_entries))) return rc;
+    if ((rc = grow((void **)&j->d_counts, &j->cap_counts, g.b_counts))) return rc;
+    if ((rc = grow((void **)&j->d_tmp, &j->cap_tmp, g.b_tmp))) return rc;
+    if ((rc = grow((void **)&j->d_partials, &j->cap_partials, g.b_partials))) return rc;
+    if ((rc = grow((void **)&j->d_chunk, &j->cap_chunk, g.b_chunk))) return rc;
     const uint32_t *d_sc = (const uint32_t *)d_scalars;
     if (scalars_on_host) {
         if ((rc = grow(&j->d_stage, &j->cap_stage, (size_t)T * n * 32))) return rc;
         BPG_CHECK_HIP(hipMemcpyAsync(j->d_stage, d_scalars, (size_t)T * n * 32, hipMemcpyHostToDevice, s));
         d_sc = (const uint32_t *)j->d_stage;
     }
-    uint32_t *counts = j->d_counts, *ent_off = counts + NE;
-    uint32_t *lvl_base = ent_off + NE;                     // level -1 (unused), then levels 0..R
-    auto lv_local = [&](int idx) { return lvl_base + (size_t)idx * lvl_words; };
-    auto lv_tot = [&](int idx) { return lvl_base + (size_t)idx * lvl_words + NE; };
-
-    const int shared = fb.c ? 1 : 0;
-    // two-level bucket sort: bins (high bucket bits), then buckets inside each bin
-    uint32_t *map0 = lvl_base + (size_t)(nlevels + 1) * lvl_words, *map1 = nlevels > 1 ? map0 + cap_lv[0] : nullptr;
-    uint32_t *bin_counts = map0 + map_words, *bin_fill = bin_counts + NBT, *bin_off = bin_fill + NBT;
-    uint32_t *chunk_off = bin_off + NBT + 1, *chunk_hist = chunk_off + NBT + 1;
-    uint2 *tmp = (uint2 *)j->d_tmp;
-    dispatch_digits(pl.c, s, d_sc, j->d_digits, n, (size_t)T * n, smap, bin_counts, (uint32_t)(2 * NBT));
-    dim3 tgrid(pl.ntiles, pl.W, T);
-    const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile,
-                       shared);
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, chunk_off, (uint32_t)NBT, CH);
-    hipLaunchKernelGGL(k_bin_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, pl.W,
-                       pl.nbin, pl.lowshift, pl.tile, shared);
-    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
-                       j->d_entries, (uint32_t)NBT, CH, LOWN);
-    // (2b and 2c have work only when some bin is larger than a chunk: modest grids that stride)
-    hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(NBT < 512 ? NBT : 512)), dim3(256), 0, s, bin_off, chunk_off, chunk_hist, counts, ent_off,
-                       (uint32_t)NBT, LOWN);
-    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(NCH < 2048 ? NCH : 2048)), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, ent_off,
-                       j->d_entries, (uint32_t)NBT, CH, LOWN);
-    // thread offsets of every pass (levels 0..R), two launches
-    hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, pl.ls0,
-                       pl.ls1);
-    hipLaunchKernelGGL(k_scan_b, dim3(nlevels + 1), dim3(1024), 0, s, lvl_base, lvl_words, NE, nblk);
-    levels_dev L{};
-    L.nlevels = nlevels;
-    for (int r = 0; r < nlevels; r++) {
-        L.lv[r] = level_ref{lv_local(r + 1), lv_tot(r + 1)};
-        L.parts[r] = j->d_partials + part_off[r];
-    }
-    // thread -> bucket maps of levels 0 and 1 (level 1 only exists when nlevels > 1)
-    hipLaunchKernelGGL(k_segmap, dim3((unsigned)((NE + 255) / 256)), dim3(256), 0, s, counts, L.lv[0], L.lv[nlevels > 1 ? 1 : 0],
-                       map0, map1, (uint32_t)NE, pl.ls0, pl.ls1);
+    const msm_bufs b{j->d_digits, j->d_entries, j->d_counts, (uint2 *)j->d_tmp, j->d_partials, j->d_chunk, j->d_out};
+    const msm_layout y = msm_lay_out(g, b);
+    msm_enqueue_sort(s, pl, g, b, y, d_sc, n, T, mm.smap, fb.c ? 1 : 0);
     // Accumulate passes of one lane's jobs run one after another: two of them at once only time-slice the
     // VALU, while the sort / merge / tail kernels of a later job do overlap usefully with an earlier job's pass.
     if (lane->acc_gate_job && lane->acc_gate_job != j) BPG_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
     BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    if (nseg > 1)
-        hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
-                           ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
-    else
-        hipLaunchKernelGGL((k_accumulate<false>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts,
-                           ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, pl.ls0, map, (uint32_t)fb.wstride);
+    msm_enqueue_accumulate(s, pl, g, b, y, mm.map, nseg > 1, (uint32_t)fb.wstride);
     BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
     lane->acc_gate_job = j;
-    const bool wide = pl.ls1 == 4 && NE <= 32768;          // latency-bound regime: 4 lanes per merge
-    for (int r = 1; r < nlevels; r++) {
-        const uint32_t *mp = r == 1 ? (const uint32_t *)map1 : (const uint32_t *)nullptr;
-        if (wide)
-            hipLaunchKernelGGL((k_reduce_wide<4>), dim3((unsigned)((cap_lv[r] * 4 + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1],
-                               L.lv[r], mp, j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk,
-                               (uint32_t)NE, r, pl.ls0);
-        else
-            hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r], mp,
-                               j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r,
-                               pl.ls0, pl.ls1);
-    }
-    ge_rec *a_out = pl.nchunks == 1 ? j->d_out : j->d_chunk;
-    hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, L, counts, a_out, pl.NB,
-                       pl.chunk, logchunk, pl.Wb, pl.ls0, pl.ls1);
-    if (pl.nchunks > 1)
-        hipLaunchKernelGGL(k_tail_b, dim3(pl.Wb, T), dim3(320), (size_t)pl.nchunks * per0 * 128, s, j->d_chunk, j->d_out,
-                           pl.nchunks, lognch, per0, pl.Wb);
+    msm_enqueue_merge_tail(s, pl, g, b, y, T);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, g.b_out, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
     release.j = nullptr;
     *out_job = j;

@@ -355,9 +355,9 @@ __global__ void __launch_bounds__(256) k_pedersen(const aniels_rec *__restrict__
                 ge_aniels q;
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
-                    q.YpX.v[t] = rec[t];
-                    q.YmX.v[t] = rec[8 + t];
-                    q.T2d.v[t] = rec[16 + t];
+                    q.hYpX.v[t] = rec[t];
+                    q.hYmX.v[t] = rec[8 + t];
+                    q.Tdxy.v[t] = rec[16 + t];
                 }
                 ge_madd(acc, acc, q, d < 0);
             }
@@ -386,9 +386,9 @@ __global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict_
     ge_aniels q;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        q.YpX.v[t] = rec[t];
-        q.YmX.v[t] = rec[8 + t];
-        q.T2d.v[t] = rec[16 + t];
+        q.hYpX.v[t] = rec[t];
+        q.hYmX.v[t] = rec[8 + t];
+        q.Tdxy.v[t] = rec[16 + t];
     }
     ge acc;
     ge_identity(acc);
@@ -401,12 +401,12 @@ __global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict_
     uint32_t *dst = comb[i].w;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        dst[t] = o.YpX.v[t];
-        dst[8 + t] = o.YmX.v[t];
-        dst[16 + t] = o.T2d.v[t];
+        dst[t] = o.hYpX.v[t];
+        dst[8 + t] = o.hYmX.v[t];
+        dst[16 + t] = o.Tdxy.v[t];
     }
     fe nt;
-    fe_neg(nt, o.T2d);
+    fe_neg(nt, o.Tdxy);
 #pragma unroll
     for (int t = 0; t < 8; t++) dst[24 + t] = nt.v[t];
 }

@@ -131,10 +131,18 @@ def v_add_nc(d, a, b, sub=False):
     return Op("%s %s, %s, %s" % ("v_sub_u32" if sub else "v_add_u32", d, a, b), [r for r in (a, b) if is_reg(r)], [d], sem)
 
 
-def v_cndmask38(d, mask):
+def v_carry_mask(d, c):
+    """d = all ones if the carry (borrow) c is set, else 0: 0 - 0 - c.  (v_cndmask_b32 with an SGPR mask measured
+    23 cycles per wave on gfx950, tools/irate.hip, against 4 for this; the v_and_b32 that follows is a 2-cycle op.)"""
     def sem(st):
-        st[d] = 38 if st[mask] else 0
-    return Op("v_cndmask_b32 %s, 0, 38, %s" % (d, mask), [], [d], sem, carry_in=mask)
+        st[d] = M32 if st[c] else 0
+    return Op("v_subb_co_u32 %s, %s, 0, 0, %s" % (d, c, c), [], [d], sem, carry_in=c, carry_out=c)
+
+
+def v_and38(d):
+    def sem(st):
+        st[d] &= 38
+    return Op("v_and_b32 %s, 38, %s" % (d, d), [d], [d], sem)
 
 
 def v_mul38(d, a):
@@ -182,7 +190,8 @@ def fe_addsub(ops, dst, a, b, carry, k, sub=False):
     ops.append(v_add_co(dst[0], carry, a[0], b[0], sub=sub))
     for i in range(1, 8):
         ops.append(v_add_co(dst[i], carry, a[i], b[i], cin=carry, sub=sub))
-    ops.append(v_cndmask38(k, carry))
+    ops.append(v_carry_mask(k, carry))
+    ops.append(v_and38(k))
     ops.append(v_add_co(dst[0], RARE, dst[0], k, sub=sub))
     ops.append(rare_ripple(dst, k, sub=sub))
 
@@ -217,10 +226,12 @@ def fe_mul(ops, dst, a, b, k):
 
 
 def build_madd():
-    """acc (X, Y, Z, T) += (A, B, C): add-2008-hwcd-3 with a precomputed point.  Where each value lives:
-         h0 = Y+X -> SPARE     t = Y-X -> X     d = 2Z -> Z
+    """acc (X, Y, Z, T) += (A, B, C) = ((y+x)/2, (y-x)/2, dxy) of the table point (or of its negative): the
+    add-2008-hwcd-3 addition with a precomputed point, every product halved (so Z stands where 2Z would).
+    Where each value lives:
+         h0 = Y+X -> SPARE     t = Y-X -> X
          a = t*B -> Y          b = h0*A -> SPARE    c = T*C -> T
-         e = b-a -> QA         h = b+a -> SPARE     f = d-c -> QB     g = d+c -> QC
+         e = b-a -> QA         h = b+a -> SPARE     f = Z-c -> QB     g = Z+c -> QC
          X = e*f   Y = g*h   T = e*h   Z = f*g      (the accumulator's registers are free by then)"""
     ops = []
     for k in range(16):
@@ -228,7 +239,6 @@ def build_madd():
     K = [Tlo(0), Tlo(1), Tlo(2), Tlo(3)]                      # scratch words of the add / sub folds (T is idle there)
     fe_addsub(ops, SPARE, Y, X, CARRY[0], K[0])
     fe_addsub(ops, X, Y, X, CARRY[1], K[1], sub=True)
-    fe_addsub(ops, Z, Z, Z, CARRY[2], K[2])
     fe_mul(ops, Y, X, QB, Thi(0))
     fe_mul(ops, SPARE, SPARE, QA, Thi(0))
     fe_mul(ops, T, T, QC, Thi(0))
@@ -370,7 +380,7 @@ def ref_madd(acc, q):
     a = (y - x) * B
     b = (y + x) * A
     c = t * C
-    d = 2 * z
+    d = z
     e, h, f, g = b - a, b + a, d - c, d + c
     return [e * f % P25519, g * h % P25519, f * g % P25519, e * h % P25519]     # X, Y, Z, T
 
@@ -403,7 +413,8 @@ def self_test(ops, order, rounds=300):
     d = (-121665 * pow(121666, P25519 - 2, P25519)) % P25519
     by = 4 * pow(5, P25519 - 2, P25519) % P25519
     bx = 15112221349535400772501151409588531511454012693041857206046113283949847762202
-    qb = [(by + bx) % P25519, (by - bx) % P25519, 2 * d * bx * by % P25519]
+    half = (P25519 + 1) // 2
+    qb = [(by + bx) * half % P25519, (by - bx) * half % P25519, d * bx * by % P25519]
     acc = [0, 1, 1, 0]
     for _ in range(20):
         acc = run(ops, order, acc, qb)
@@ -432,7 +443,7 @@ def emit(ops, order, path):
 // results against Python integers on random and edge-case inputs, and the two-wait-state rule on every carry read).
 // Do not edit by hand; edit the generator and run it again.
 //
-// p += q for an extended point p and a table entry q = (A, B, C) = (y+x, y-x, 2dxy) of +P or (y-x, y+x, -2dxy) of -P.
+// p += q for an extended point p and a table entry q = (A, B, C) = ((y+x)/2, (y-x)/2, dxy) of +P or ((y-x)/2, (y+x)/2, -dxy) of -P.
 // %d instructions: %d v_mad_u64_u32, %d other VALU, %d s_nop.  Scratch: v%d..v%d, s94..s101, vcc (clobbers).
 // q is overwritten (its registers hold e, f, g once A, B, C have been consumed).
 __device__ __forceinline__ void gez_madd_asm(ge &p, ge_aniels_signed &q) {

@@ -159,9 +159,9 @@ __global__ void __launch_bounds__(256) k_madd(fe *out, const fe *in) {
     ge acc;
     ge_identity(acc);
     ge_aniels q;
-    q.YpX = in[i];
-    q.YmX = in[i + 1];
-    q.T2d = in[i + 2];
+    q.hYpX = in[i];
+    q.hYmX = in[i + 1];
+    q.Tdxy = in[i + 2];
     for (int k = 0; k < GE_ITERS; k++) ge_madd(acc, acc, q, (k & 1) != 0);
     out[i] = acc.X;
     out[i + 1] = acc.Y;
@@ -247,9 +247,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         const bool neg = (k % 3) == 1;
         if (FORM == 0) {
             ge_aniels qq;
-            qq.YpX = in[i + 4 + k];
-            qq.YmX = in[i + 5 + k];
-            qq.T2d = in[i + 6 + k];
+            qq.hYpX = in[i + 4 + k];
+            qq.hYmX = in[i + 5 + k];
+            qq.Tdxy = in[i + 6 + k];
             ge_madd(a, a, qq, neg);
         } else {
             ge_aniels_signed s;
@@ -304,13 +304,13 @@ __global__ void __launch_bounds__(256) k_madd_stamped(fe *out, const fe *in, uin
     ge acc;
     ge_identity(acc);
     ge_aniels q;
-    q.YpX = in[i];
-    q.YmX = in[i + 1];
-    q.T2d = in[i + 2];
+    q.hYpX = in[i];
+    q.hYmX = in[i + 1];
+    q.Tdxy = in[i + 2];
     uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int k = 0; k < iters; k++) {
         ge_madd(acc, acc, q, (k & 1) != 0);
-        q.T2d.v[0] ^= acc.X.v[0];          // keep the operand varying
+        q.Tdxy.v[0] ^= acc.X.v[0];          // keep the operand varying
     }
     uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[i] = acc.X;
