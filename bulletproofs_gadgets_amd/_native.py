@@ -68,6 +68,7 @@ def lib():
         "bpg_msm_plan": (ctypes.c_int, [vp, sz, sz, ip, ip, ip, ip]),
         "bpg_msm_last_kernel_us": (ctypes.c_int, [vp, fp, fp]),
         "bpg_debug_fail_alloc": (None, [ctypes.c_int]),
+        "bpg_msm_noalloc": (ctypes.c_int, [vp, vp, vp, sz, vp, vp]),
     }
     u64p, dp = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)
     ci = ctypes.c_int
@@ -277,6 +278,10 @@ class Context:
             check(lib().bpg_msm_submit_segments(self._h, points._h, starts, lens, k, d_scalars_ptr, n_targets,
                                                 ctypes.byref(h)))
         return MsmJob(self, h.value, n_targets)
+
+    def msm_noalloc(self, points, d_scalars_ptr, n, d_out_ptr, stream=None):
+        """bpg_msm_noalloc: enqueue on `stream` (a hipStream_t as an int, None = null stream); result lands in device memory"""
+        check(lib().bpg_msm_noalloc(self._h, points._h, d_scalars_ptr, n, d_out_ptr, stream))
 
     def msm_plan(self, n, n_targets=1):
         c, w, nb, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

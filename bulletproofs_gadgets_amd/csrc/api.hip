@@ -299,6 +299,10 @@ int bpg_init(int device_id, bpg_ctx **out) {
     if (const char *s = getenv("BPG_MSM_LS1")) ctx->tune.ls1 = atoi(s);
     if (const char *s = getenv("BPG_MSM_SORT_CHUNK")) ctx->tune.sort_chunk = atoi(s);
     if (const char *s = getenv("BPG_IPP_FOLD")) ctx->tune.ipp_fold = atoi(s);
+    if (int rc = msm_noalloc_init(ctx)) {                  // address of this device's static workspace (bpg_msm_noalloc)
+        delete ctx;
+        return rc;
+    }
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.push_back(ctx);
@@ -465,6 +469,12 @@ int bpg_msm(bpg_ctx *ctx, const bpg_points *pts, const uint8_t *scalars32, size_
         return rc;
     }
     return msm_wait(job, out32, false);
+}
+
+int bpg_msm_noalloc(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, size_t n, void *d_out32, void *stream) {
+    if (!ctx || !pts || n > pts->n) return BPG_EINVAL;
+    msm_seg seg{pts->d_table, n};
+    return msm_noalloc(ctx, &seg, d_scalars, n, d_out32, (hipStream_t)stream);
 }
 
 int bpg_msm_plan(bpg_ctx *ctx, size_t n, size_t n_targets, int *window_bits, int *windows, int *buckets, int *threads_per_bucket) {

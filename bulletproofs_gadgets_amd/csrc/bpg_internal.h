@@ -140,6 +140,9 @@ struct bpg_ctx {
     std::mutex mu;                    // guards lanes, free_lanes
     std::vector<bpg_lane *> lanes;
     std::vector<bpg_lane *> free_lanes;   // lanes of threads that have exited: the next new thread takes one over
+    // this device's copy of the static workspace of bpg_msm_noalloc (msm.hip: msm_noalloc_init)
+    void *noalloc_scratch = nullptr;
+    size_t noalloc_scratch_bytes = 0;
 };
 
 namespace bpg {
@@ -170,6 +173,8 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
 // table holds W * npts records with records [0, npts) filled: fills [w * npts + i] = 2^(c w) P_i
 int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int W);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);
+int msm_noalloc_init(bpg_ctx *ctx);
+int msm_noalloc(bpg_ctx *ctx, const msm_seg *seg, const void *d_scalars, size_t n, void *d_out32, hipStream_t s);
 int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, size_t stride, int rows, size_t np, size_t m,
                     msm_fixed_base fb, aniels_rec *d_tab, bpg_msm_job **out_job);
 int msm_fold_wait(bpg_msm_job *job);

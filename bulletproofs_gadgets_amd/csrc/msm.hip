@@ -1456,6 +1456,113 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     return BPG_OK;
 }
 
+// ------------------------------------------------------------------ the entry point that allocates nothing
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+// it).  The same kernels as msm_submit(), with the workspace carved out of a file-scope device array instead of a
+// job's growable buffers, everything enqueued on the caller's stream, no events, no lanes, no host buffer: the
+// window combination that msm_wait() does on the host runs in k_tail_final on the device and the 32-byte encoding
+// is written to the caller's device pointer.  Each GPU holds its own copy of the array for the life of the process.
+constexpr size_t NOALLOC_MAX_POINTS = BPG_MSM_NOALLOC_MAX_POINTS;
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)20 << 20;        // covers n = 16384 at any window the planner picks (checked per call)
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+// `scratch` in host code is a stand-in, not a device address: the per-device address comes from the runtime, once
+// per context (= per device), with that device current (called by bpg_init).
+int msm_noalloc_init(bpg_ctx *ctx) {
+    void *ptr = nullptr;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    BPG_CHECK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    ctx->noalloc_scratch = ptr;
+    ctx->noalloc_scratch_bytes = NOALLOC_SCRATCH_BYTES;
+    return BPG_OK;
+}
+
+// One wave per target.  Lane w < Wb takes bucket set w = [total, S_0 .. S_{c-2}] to V_w = total + sum_j 2^j S_j
+// (Horner over the bit sums), then lane 0 walks sum_w 2^(c w) V_w from the top window down and compresses.
+// (One dependent chain of c * Wb doublings: about a millisecond on one lane.  msm_wait() does this on a host core.)
+__global__ void __launch_bounds__(64) k_tail_final(const ge_rec *__restrict__ sets, int C, int Wb, uint8_t *__restrict__ out32) {
+    __shared__ ge_rec v[64];
+    const int w = threadIdx.x;
+    const ge_rec *base = sets + (size_t)blockIdx.x * Wb * C;
+    if (w < Wb) {
+        ge acc, t;
+        ge_identity(acc);
+        for (int j = C - 2; j >= 0; j--) {
+            ge_double(acc, acc);
+            load_ge(t, base + (size_t)w * C + 1 + j);
+            ge_add(acc, acc, t);
+        }
+        load_ge(t, base + (size_t)w * C);
+        ge_add(acc, acc, t);
+        store_ge(&v[w], acc);
+    }
+    __syncthreads();
+    if (w != 0) return;
+    ge acc, t;
+    ge_identity(acc);
+    for (int k = Wb - 1; k >= 0; k--) {
+        if (k != Wb - 1)
+            for (int d = 0; d < C; d++) ge_double(acc, acc);
+        load_ge(t, &v[k]);
+        ge_add(acc, acc, t);
+    }
+    uint32_t enc[8];
+    ristretto_encode_w(enc, acc);
+    uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * (size_t)blockIdx.x);
+    o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
+    o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
+}
+
+int msm_noalloc(bpg_ctx *ctx, const msm_seg *seg, const void *d_scalars, size_t n, void *d_out32, hipStream_t s) {
+    if (!ctx || !seg || !d_out32 || (n && !d_scalars)) return BPG_EINVAL;
+    if (n > NOALLOC_MAX_POINTS) {
+        set_last_error_msg("bpg_msm_noalloc: more than BPG_MSM_NOALLOC_MAX_POINTS points (use bpg_msm_submit)");
+        return BPG_EINVAL;
+    }
+    if (!ctx->noalloc_scratch) return BPG_EDEVICE;
+    BPG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {                                          // the identity encodes as 32 zero bytes
+        BPG_CHECK_HIP(hipMemsetAsync(d_out32, 0, 32, s));
+        return BPG_OK;
+    }
+    msm_maps mm{};
+    int rc;
+    if ((rc = msm_make_maps(seg, 1, n, 0, mm))) return rc;
+    // the automatic window for n, whatever BPG_MSM_* overrides the context carries: the bound on the workspace
+    // (12.9 MiB at n = 16384) holds for the planner's own choice
+    const msm_plan pl = make_plan(n, 1, msm_tuning(), 0, 1.f, ctx->resident_lanes);
+    msm_geom g{};
+    if ((rc = msm_geometry(pl, n, 1, g))) return rc;
+    if (pl.Wb > 64) return BPG_EINVAL;                     // k_tail_final: one lane per window
+    // carve the workspace (256-byte aligned pieces); everything the kernels read before writing is (re)initialised
+    // by the kernels themselves (k_digits clears the sort's counters), so the last call's contents do not matter
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *p = (uint8_t *)ctx->noalloc_scratch + off;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    msm_bufs b{};
+    b.digits = (int16_t *)take(g.b_digits);
+    b.entries = (uint32_t *)take(g.b_entries);
+    b.counts = (uint32_t *)take(g.b_counts);
+    b.tmp = (uint2 *)take(g.b_tmp);
+    b.partials = (ge_rec *)take(g.b_partials);
+    b.chunk = (ge_rec *)take(g.b_chunk);
+    b.out = (ge_rec *)take(g.b_out);
+    if (off > ctx->noalloc_scratch_bytes) {
+        set_last_error_msg("bpg_msm_noalloc: workspace for this size exceeds the static device array");
+        return BPG_EINVAL;
+    }
+    const msm_layout y = msm_lay_out(g, b);
+    msm_enqueue_sort(s, pl, g, b, y, (const uint32_t *)d_scalars, n, 1, mm.smap, 0);
+    msm_enqueue_accumulate(s, pl, g, b, y, mm.map, false, 0u);
+    msm_enqueue_merge_tail(s, pl, g, b, y, 1);
+    hipLaunchKernelGGL(k_tail_final, dim3(1), dim3(64), 0, s, (const ge_rec *)b.out, pl.outs, pl.Wb, (uint8_t *)d_out32);
+    BPG_CHECK_HIP(hipGetLastError());
+    return BPG_OK;
+}
+
 // Folded generators (see k_fold_hist): rows scalar rows [s_G (np) | s_H (np)] `stride` scalars apart, the fixed-base
 // tables of G[0..np) and H[0..np) in segs[0], segs[1]; writes rows * 2m affine Niels records
 // [row][G'_0 .. G'_{m-1} | H'_0 .. H'_{m-1}] to d_tab (device).  Asynchronous: msm_fold_wait(job).

@@ -91,6 +91,20 @@ int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, s
                    bpg_msm_job **job);
 int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32);
 
+/* The entry point that allocates nothing.  No counterpart in the reference: it is for callers that cannot call
+ * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same result as
+ * bpg_msm_submit + bpg_msm_wait with one target: d_out32[0..32) = compress( sum_i d_scalars[i] * pts[i] ), i < n.
+ * d_scalars and d_out32 are DEVICE pointers, `stream` a hipStream_t (NULL: the null stream); every kernel is enqueued
+ * on that stream and the call returns without synchronising: the result is there when the stream reaches that point.
+ * No hipMalloc / hipFree / stream / event creation, no host buffer: the kernels' workspace is a static device array of
+ * 20 MiB inside the library (each GPU the library runs on holds it until the process ends), which limits
+ * n <= BPG_MSM_NOALLOC_MAX_POINTS; beyond that BPG_EINVAL (use bpg_msm_submit).  All calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two threads, two contexts on the same device) race; issue them
+ * on one stream or order them yourself.  The window combination that bpg_msm_wait does on a host core runs on one
+ * GPU lane here (about a millisecond): the variant trades latency for not allocating. */
+#define BPG_MSM_NOALLOC_MAX_POINTS 16384
+int bpg_msm_noalloc(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, size_t n, void *d_out32, void *stream);
+
 /* Point-range sharding (one large MSM split over the GPUs of a node):
  * each rank runs its range with bpg_msm_submit(), takes its partial sums with
  * bpg_msm_wait_partial() (n_targets x 128 B: extended coordinates X|Y|Z|T,
