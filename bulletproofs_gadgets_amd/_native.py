@@ -27,6 +27,7 @@ class BpgError(RuntimeError):
 _lib = None
 # bpg_rng_fn: void (*)(void *user, uint8_t *out, size_t n)
 RNG_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
+RANDOMIZED_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 
@@ -98,6 +99,8 @@ def lib():
         "bpg_cs_multiply": (ci, [vp, u64p, cp, sz, u64p, cp, sz, u64p]),
         "bpg_cs_allocate_multiplier": (ci, [vp, cp, cp, u64p]),
         "bpg_cs_constrain": (ci, [vp, u64p, cp, sz]),
+        "bpg_cs_specify_randomized_constraints": (ci, [vp, RANDOMIZED_FN, vp]),
+        "bpg_cs_challenge_scalar": (ci, [vp, cp, sz, cp]),
         "bpg_cs_export_terms": (ci, [vp, u64p, vp, ctypes.POINTER(ctypes.c_uint32), sz, psz]),
         "bpg_gadget_binary_constrain": (ci, [vp, ctypes.c_uint64]),
         "bpg_gadget_nonzero": (ci, [vp, u64p, cp, sz, cp]),

@@ -616,6 +616,7 @@ class Transcript {
     }
     void r1cs_domain_sep() { append_message("dom-sep", "r1cs v1", 7); }
     void r1cs_1phase_domain_sep() { append_message("dom-sep", "r1cs-1phase", 11); }
+    void r1cs_2phase_domain_sep() { append_message("dom-sep", "r1cs-2phase", 11); }
     void innerproduct_domain_sep(uint64_t n) {
         append_message("dom-sep", "ipp v1", 6);
         append_u64("n", n);

@@ -12,7 +12,9 @@
 //                                 ref: edwards_point.rs:45; scalar.rs:10-21; boolean.rs:20
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
+#include <string>
 #include <stdexcept>
 #include <unordered_map>
 #include <vector>
@@ -197,6 +199,15 @@ class ConstraintSystem {
     virtual Triple allocate_multiplier(const Scalar *left, const Scalar *right) = 0;
     virtual void constrain(const LinearCombination &lc) = 0;
     virtual bool is_prover() const = 0;
+    // RandomizableConstraintSystem::specify_randomized_constraints / RandomizedConstraintSystem::challenge_scalar
+    // (bulletproofs::r1cs, feature yoloproofs; the reference imports RandomizedConstraintSystem at
+    // src/gadgets/point/ristretto_point.rs:3 and registers none).  The callback runs inside prove() / verify(),
+    // after the first-phase commitments A_I1, A_O1, S1 are in the transcript; it may draw challenges, allocate
+    // multipliers (the second phase, committed in A_I2, A_O2, S2) and add constraints.
+    using RandomizedFn = std::function<void(ConstraintSystem &)>;
+    virtual void specify_randomized_constraints(RandomizedFn cb) = 0;
+    // only inside a randomized-constraints callback; throws R1CSError(BPG_EINVAL) elsewhere
+    virtual Scalar challenge_scalar(const std::string &label) = 0;
     // what a Variable may refer to: multipliers allocated and values committed so far
     virtual size_t num_multipliers() const = 0;
     virtual size_t num_committed() const = 0;
@@ -260,6 +271,8 @@ class Prover : public ConstraintSystem {
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, a_L_.size(), v_.size()); }
     bool is_prover() const override { return true; }
+    void specify_randomized_constraints(RandomizedFn cb) override { deferred_.push_back(std::move(cb)); }
+    Scalar challenge_scalar(const std::string &label) override;
     Scalar eval(const LinearCombination &lc) const;
     // Prover::prove(bp_gens); returns BPG_OK or a negative BPG_E* code
     int prove(rng_fill_fn rng, void *rng_user, R1CSProof &out);
@@ -280,6 +293,13 @@ class Prover : public ConstraintSystem {
     void draw_blindings();
     int prove_finish(R1CSProof &out);
     static int finish_group(Prover *const *ps, size_t g, R1CSProof *out);
+    // randomized constraints: first-phase commitments, the deferred callbacks, second-phase commitments
+    int two_phase_prologue(R1CSProof &out);
+    int commit3(size_t lo, size_t hi, const sc bl[3], const sc *sL, const sc *sR, uint8_t out96[96]);
+    std::vector<RandomizedFn> deferred_;
+    bool phase2_ = false, two_phase_done_ = false;
+    size_t n1_ = 0;                       // multipliers of the first phase (all of them without randomized constraints)
+    sc i_bl2_, o_bl2_, s_bl2_;            // second-phase blindings (zero without a second phase)
     Gens *gens_;
     Transcript tr_;
     ConstraintStore cs_;
@@ -308,6 +328,8 @@ class Verifier : public ConstraintSystem {
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, num_vars_, V_.size() / 32); }
     bool is_prover() const override { return false; }
+    void specify_randomized_constraints(RandomizedFn cb) override { deferred_.push_back(std::move(cb)); }
+    Scalar challenge_scalar(const std::string &label) override;
     // Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng); BPG_OK or BPG_EVERIFY / BPG_EGENS / ...
     int verify(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user);
     int prepare(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user, VerifyRow &out);
@@ -321,6 +343,8 @@ class Verifier : public ConstraintSystem {
     ConstraintStore cs_;
     size_t num_vars_ = 0;
     std::vector<uint8_t> V_;
+    std::vector<RandomizedFn> deferred_;
+    bool phase2_ = false;
 };
 
 // k proofs, one combined multiscalar multiplication (BASELINE config 5); BPG_OK iff all verify

@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(256) k_poly(uint32_t n, const poly_group G) {
 // l(x), r(x) -> the IPP's a, b (length np, padded), and the generator factor vectors
 //   sG_j = G_factors[j] = 1 (j < n) | u (pad)      sH_j = y^-j * G_factors[j]
 struct eval_proof {
+    uint32_t n1;             // multipliers of the first phase: G_factors = 1 below n1, u from n1 on (second phase and padding)
     sc x, u;
     const sc *l1, *aO, *sL, *r0, *r1, *r3, *ytbl, *yinvtbl;
     sc *a, *b, *sG, *sH;
@@ -182,8 +183,8 @@ __global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, const eva
         sc r = add_(ld_sc(r0 + i), mul_(x, add_(ld_sc(r1 + i), mul_(x, mul_(x, ld_sc(r3 + i))))));
         st_sc(a + i, l);
         st_sc(b + i, r);
-        st_sc(sG + i, sc_one());
-        st_sc(sH + i, yinvi);
+        st_sc(sG + i, i < P.n1 ? sc_one() : u);
+        st_sc(sH + i, i < P.n1 ? yinvi : mul_(yinvi, u));
     } else {
         sc yi = pow_tbl(ytbl, i), neg;
         sc_neg(neg, yi);
@@ -280,7 +281,7 @@ __global__ void __launch_bounds__(256) k_ipp_fold(uint32_t np, uint32_t nk, cons
 //   g_i = ufor_i (x y^-i wR_i - a s_i)      h_i = ufor_i (y^-i (x wL_i + wO_i - b s_{np-1-i}) - 1)
 struct verify_args {
     sc x, a, b, u;
-    uint32_t n, np, lg;
+    uint32_t n, np, lg, n1;     // n1: multipliers of the first phase (u multiplies the scalars from n1 on)
 };
 __global__ void __launch_bounds__(256) k_verify_scalars(verify_args A, const sc *__restrict__ W, const sc *__restrict__ yinvtbl,
                                                         const sc *__restrict__ uk, const sc *__restrict__ ukinv,
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) k_verify_scalars(verify_args A, const sc 
         d[0] = mul_(yneg_wR, wL);
         sc gi = sub_(mul_(A.x, yneg_wR), mul_(A.a, s));
         sc hi = sub_(mul_(yinvi, sub_(add_(mul_(A.x, wL), wO), mul_(A.b, srev))), sc_one());
-        if (i >= A.n) {
+        if (i >= A.n1) {
             gi = mul_(gi, A.u);
             hi = mul_(hi, A.u);
         }
@@ -875,17 +876,102 @@ ConstraintSystem::Triple Prover::allocate_multiplier(const Scalar *left, const S
     return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
 }
 
-// Inner-product round after which finish_group materializes the folded generators (0: never; BPG_IPP_FOLD
-// overrides): when 2 x 2048 folded generators are left.  The fold costs about 3.4 rounds' worth of additions
-// whenever it is done; measured at 2^16 multipliers, 16 threads x 8 statements: 204-210 proofs/s without,
-// 211 / 246 / 242 after round 4 / 5 / 6.
-static int ipp_fold_default(size_t lg) { return lg >= 12 ? (int)lg - 11 : 0; }
-
 static inline size_t next_pow2(size_t n) {
     size_t p = 1;
     while (p < n) p <<= 1;
     return p;
 }
+
+Scalar Prover::challenge_scalar(const std::string &label) {
+    if (!phase2_) throw R1CSError(BPG_EINVAL, "challenge_scalar outside a randomized-constraints callback");
+    return Scalar(tr_.challenge_scalar(label.c_str()));
+}
+
+// A_I, A_O, S over the multipliers [lo, hi): <a_L, G[lo..hi)> + <a_R, H[lo..hi)> + bl[0] B~, <a_O, G> + bl[1] B~,
+// <s_L, G> + <s_R, H> + bl[2] B~ -- one 3-target MSM.  (Two-phase proofs only; the usual path commits inside finish_group.)
+int Prover::commit3(size_t lo, size_t hi, const sc bl[3], const sc *sL, const sc *sR, uint8_t out96[96]) {
+    bpg_lane *lane = lane_of(gens_->ctx);
+    if (!lane) return BPG_EDEVICE;
+    hipStream_t s = lane->stream;
+    const size_t k = hi - lo, N1 = 2 * k + 1;
+    Arena ar(lane);
+    int rc = ar.reserve(3 * N1 * 32 + 4096);
+    if (rc) return rc;
+    sc *rows = ar.take<sc>(3 * N1);
+    BPG_CHECK_HIP(hipMemsetAsync(rows, 0, 3 * N1 * 32, s));
+    for (int t = 0; t < 3; t++) BPG_CHECK_HIP(hipMemcpyAsync(rows + t * N1, &bl[t], 32, hipMemcpyHostToDevice, s));
+    if (k) {
+        BPG_CHECK_HIP(hipMemcpyAsync(rows + 1, a_L_.data() + lo, k * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(rows + 1 + k, a_R_.data() + lo, k * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(rows + N1 + 1, a_O_.data() + lo, k * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(rows + 2 * N1 + 1, sL, k * 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(rows + 2 * N1 + 1 + k, sR, k * 32, hipMemcpyHostToDevice, s));
+    }
+    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    msm_seg segs[3] = {pedersen_seg(gens_, 1, 1, 0), gen_seg(gens_, 0, lo, hi, 1), gen_seg(gens_, 1, lo, hi, 1 + k)};
+    return gens_msm(gens_, segs, 3, rows, N1, 3, out96);
+}
+
+// Randomized constraints (bulletproofs r1cs, two-phase): commit to the first-phase wires, let the deferred callbacks
+// draw their challenges and build the second phase, commit to its wires.  Leaves the transcript where the one-phase
+// path has it before the challenges y, z; s_L_ / s_R_ then cover both phases.
+int Prover::two_phase_prologue(R1CSProof &P) {
+    const size_t n1 = a_L_.size();
+    n1_ = n1;
+    uint8_t o[96];
+    const sc bl1[3] = {i_bl_, o_bl_, s_bl_};
+    int rc = commit3(0, n1, bl1, s_L_.data(), s_R_.data(), o);
+    if (rc) return rc;
+    memcpy(P.A_I1, o, 32);
+    memcpy(P.A_O1, o + 32, 32);
+    memcpy(P.S1, o + 64, 32);
+    tr_.append_point("A_I1", P.A_I1);
+    tr_.append_point("A_O1", P.A_O1);
+    tr_.append_point("S1", P.S1);
+    tr_.r1cs_2phase_domain_sep();
+    std::vector<RandomizedFn> cbs;
+    cbs.swap(deferred_);
+    phase2_ = true;
+    try {
+        for (auto &cb : cbs) cb(*this);
+    } catch (...) {
+        phase2_ = false;
+        throw;
+    }
+    phase2_ = false;
+    const size_t n = a_L_.size(), n2 = n - n1;
+    if (gens_->capacity < next_pow2(n ? n : 1)) return BPG_EGENS;
+    if (n2) {
+        i_bl2_ = rng_->scalar();
+        o_bl2_ = rng_->scalar();
+        s_bl2_ = rng_->scalar();
+        s_L_.resize(n);
+        s_R_.resize(n);
+        for (size_t i = n1; i < n; i++) s_L_[i] = rng_->scalar();
+        for (size_t i = n1; i < n; i++) s_R_[i] = rng_->scalar();
+        const sc bl2[3] = {i_bl2_, o_bl2_, s_bl2_};
+        if ((rc = commit3(n1, n, bl2, s_L_.data() + n1, s_R_.data() + n1, o))) return rc;
+        memcpy(P.A_I2, o, 32);
+        memcpy(P.A_O2, o + 32, 32);
+        memcpy(P.S2, o + 64, 32);
+    } else {
+        i_bl2_ = o_bl2_ = s_bl2_ = sc_zero();
+        memset(P.A_I2, 0, 32);
+        memset(P.A_O2, 0, 32);
+        memset(P.S2, 0, 32);
+    }
+    tr_.append_point("A_I2", P.A_I2);
+    tr_.append_point("A_O2", P.A_O2);
+    tr_.append_point("S2", P.S2);
+    two_phase_done_ = true;
+    return BPG_OK;
+}
+
+// Inner-product round after which finish_group materializes the folded generators (0: never; BPG_IPP_FOLD
+// overrides): when 2 x 2048 folded generators are left.  The fold costs about 3.4 rounds' worth of additions
+// whenever it is done; measured at 2^16 multipliers, 16 threads x 8 statements: 204-210 proofs/s without,
+// 211 / 246 / 242 after round 4 / 5 / 6.
+static int ipp_fold_default(size_t lg) { return lg >= 12 ? (int)lg - 11 : 0; }
 
 int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     int rc = prove_begin(rng_fn, rng_user);
@@ -970,7 +1056,9 @@ int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rn
     const size_t gmax = 8;
     for (size_t j0 = 0; j0 < k;) {
         size_t g = 1;
-        while (j0 + g < k && g < gmax && ps[j0 + g]->a_L_.size() == ps[j0]->a_L_.size() && ps[j0 + g]->gens_ == ps[j0]->gens_) g++;
+        while (j0 + g < k && g < gmax && ps[j0 + g]->a_L_.size() == ps[j0]->a_L_.size() && ps[j0 + g]->gens_ == ps[j0]->gens_ &&
+               ps[j0]->deferred_.empty() && ps[j0 + g]->deferred_.empty())       // randomized constraints: one prover at a time
+            g++;
         int rc = finish_group(ps + j0, g, out + j0);
         if (rc) return rc;
         j0 += g;
@@ -1003,6 +1091,16 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
+    for (size_t j = 0; j < g; j++) {
+        ps[j]->n1_ = ps[j]->a_L_.size();
+        ps[j]->i_bl2_ = ps[j]->o_bl2_ = ps[j]->s_bl2_ = sc_zero();
+    }
+    if (!ps[0]->deferred_.empty()) {
+        if (g != 1) return BPG_EINVAL;
+        int rc2 = ps[0]->two_phase_prologue(out[0]);
+        if (rc2) return rc2;
+    }
+    const bool two_phase = ps[0]->two_phase_done_;
     const size_t n = ps[0]->a_L_.size();
     for (size_t j = 1; j < g; j++)
         if (ps[j]->a_L_.size() != n || ps[j]->gens_ != gens) return BPG_EINVAL;
@@ -1068,7 +1166,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
     // ---- A_I1, A_O1, S1 of every proof: one 3g-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
-    {
+    if (!two_phase) {
         msm_seg segs[3] = {pedersen_seg(gens, 1, 1, 0), gen_seg(gens, 0, 0, n, 1), gen_seg(gens, 1, 0, n, 1 + n)};
         std::vector<uint8_t> o(96 * g);
         if ((rc = gens_msm(gens, segs, 3, d_rows_all, N1, (int)(3 * g), o.data()))) return rc;
@@ -1090,16 +1188,18 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         R1CSProof &P = out[j];
         const size_t m = p.v_.size();
         p.timing.commit_ms = commit_ms;
-        p.tr_.append_point("A_I1", P.A_I1);
-        p.tr_.append_point("A_O1", P.A_O1);
-        p.tr_.append_point("S1", P.S1);
-        p.tr_.r1cs_1phase_domain_sep();          // the reference's gadgets register no randomized constraints
-        memset(P.A_I2, 0, 32);
-        memset(P.A_O2, 0, 32);
-        memset(P.S2, 0, 32);
-        p.tr_.append_point("A_I2", P.A_I2);
-        p.tr_.append_point("A_O2", P.A_O2);
-        p.tr_.append_point("S2", P.S2);
+        if (!two_phase) {                        // (two_phase_prologue has done all of this for a two-phase proof)
+            p.tr_.append_point("A_I1", P.A_I1);
+            p.tr_.append_point("A_O1", P.A_O1);
+            p.tr_.append_point("S1", P.S1);
+            p.tr_.r1cs_1phase_domain_sep();      // no randomized constraints (none of the reference's gadgets registers any)
+            memset(P.A_I2, 0, 32);
+            memset(P.A_O2, 0, 32);
+            memset(P.S2, 0, 32);
+            p.tr_.append_point("A_I2", P.A_I2);
+            p.tr_.append_point("A_O2", P.A_O2);
+            p.tr_.append_point("S2", P.S2);
+        }
         f.y = p.tr_.challenge_scalar("y");
         f.z = p.tr_.challenge_scalar("z");
         f.d_W = ar.take<sc>(f.fp.nslots + 1);
@@ -1174,7 +1274,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         for (size_t i = 0; i < m; i++) tb[2] += Scalar(f.wV[i]) * Scalar(p.v_blinding_[i]);
         P.t_x = x * (t[1] + x * (t[2] + x * (t[3] + x * (t[4] + x * (t[5] + x * t[6])))));
         P.t_x_blinding = x * (tb[1] + x * (tb[2] + x * (tb[3] + x * (tb[4] + x * (tb[5] + x * tb[6])))));
-        P.e_blinding = x * (Scalar(p.i_bl_) + x * (Scalar(p.o_bl_) + x * Scalar(p.s_bl_)));   // second-phase blindings are zero
+        const Scalar ibl = Scalar(p.i_bl_) + f.u * Scalar(p.i_bl2_), obl = Scalar(p.o_bl_) + f.u * Scalar(p.o_bl2_),
+                     sbl = Scalar(p.s_bl_) + f.u * Scalar(p.s_bl2_);
+        P.e_blinding = x * (ibl + x * (obl + x * sbl));
         p.tr_.append_scalar("t_x", P.t_x.v);
         p.tr_.append_scalar("t_x_blinding", P.t_x_blinding.v);
         p.tr_.append_scalar("e_blinding", P.e_blinding.v);
@@ -1185,7 +1287,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.d_sH = f.d_sG + np;
         f.d_cpart = ar.take<sc>(nblk_np * 2);
         f.d_rowLR = d_rowLR_all + j * 2 * NR;
-        egrp.p[j] = eval_proof{f.x.v, f.u.v, f.d_l1, f.d_aO, f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH};
+        egrp.p[j] = eval_proof{(uint32_t)p.n1_, f.x.v, f.u.v, f.d_l1, f.d_aO, f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH};
         p.tr_.innerproduct_domain_sep(np);
         P.L_vec.assign(32 * lg, 0);
         P.R_vec.assign(32 * lg, 0);
@@ -1281,6 +1383,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         p.timing.ipp_ms = ipp_ms;
         p.timing.total_ms = t_end - p.t_start_;
         p.rng_.reset();
+        p.two_phase_done_ = false;
     }
     return BPG_OK;
 }
@@ -1306,6 +1409,11 @@ ConstraintSystem::Triple Verifier::multiply(LinearCombination left, LinearCombin
     return t;
 }
 
+Scalar Verifier::challenge_scalar(const std::string &label) {
+    if (!phase2_) throw R1CSError(BPG_EINVAL, "challenge_scalar outside a randomized-constraints callback");
+    return Scalar(tr_.challenge_scalar(label.c_str()));
+}
+
 ConstraintSystem::Triple Verifier::allocate_multiplier(const Scalar *, const Scalar *) {
     uint32_t i = (uint32_t)num_vars_++;
     return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
@@ -1320,15 +1428,30 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     bpg_lane *lane = lane_of(ctx);
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
-    const size_t n = num_vars_, m = V_.size() / 32;
-    const size_t np = next_pow2(n ? n : 1);
-    size_t lg = 0;
-    while (((size_t)1 << lg) < np) lg++;
+    const size_t n1 = num_vars_, m = V_.size() / 32;
     tr_.append_u64("m", m);
     if (!tr_.validate_and_append_point("A_I1", P.A_I1) || !tr_.validate_and_append_point("A_O1", P.A_O1) ||
         !tr_.validate_and_append_point("S1", P.S1))
         return BPG_EVERIFY;
-    tr_.r1cs_1phase_domain_sep();
+    if (deferred_.empty()) {
+        tr_.r1cs_1phase_domain_sep();
+    } else {                                     // randomized constraints: the callbacks build the second phase now
+        tr_.r1cs_2phase_domain_sep();
+        std::vector<RandomizedFn> cbs;
+        cbs.swap(deferred_);
+        phase2_ = true;
+        try {
+            for (auto &cb : cbs) cb(*this);
+        } catch (...) {
+            phase2_ = false;
+            throw;
+        }
+        phase2_ = false;
+    }
+    const size_t n = num_vars_;
+    const size_t np = next_pow2(n ? n : 1);
+    size_t lg = 0;
+    while (((size_t)1 << lg) < np) lg++;
     if (gens->capacity < np) return BPG_EGENS;
     tr_.append_point("A_I2", P.A_I2);
     tr_.append_point("A_O2", P.A_O2);
@@ -1396,7 +1519,7 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     BPG_CHECK_HIP(hipMemcpyAsync(d_yinvtbl, yinvtbl, sizeof yinvtbl, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipMemcpyAsync(d_uk, uk.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
     BPG_CHECK_HIP(hipMemcpyAsync(d_ukinv, ukinv.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
-    verify_args A{x.v, P.a.v, P.b.v, u.v, (uint32_t)n, (uint32_t)np, (uint32_t)lg};
+    verify_args A{x.v, P.a.v, P.b.v, u.v, (uint32_t)n, (uint32_t)np, (uint32_t)lg, (uint32_t)n1};
     // scalar row order = table order: [ g (G) | h (H) | B | B~ | dyn ]
     hipLaunchKernelGGL(k_verify_scalars, dim3((unsigned)nblk), dim3(256), 0, s, A, d_W, d_yinvtbl, d_uk, d_ukinv, d_sc, d_sc + np,
                        d_part);

@@ -295,6 +295,28 @@ int bpg_cs_constrain(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, si
     });
 }
 
+int bpg_cs_specify_randomized_constraints(bpg_cs *cs, bpg_randomized_fn callback, void *user) {
+    if (!cs || !callback) return BPG_EINVAL;
+    return guarded([&] {
+        cs->cs->specify_randomized_constraints([callback, user](ConstraintSystem &rcs) {
+            bpg_cs handle{&rcs};
+            const int rc = callback(user, &handle);
+            if (rc) throw R1CSError(rc, "randomized-constraints callback failed");
+        });
+        return BPG_OK;
+    });
+}
+int bpg_cs_challenge_scalar(bpg_cs *rcs, const uint8_t *label, size_t label_len, uint8_t out32[32]) {
+    if (!rcs || !out32 || (label_len && !label)) return BPG_EINVAL;
+    return guarded([&] {
+        // merlin labels are byte strings without NUL bytes (Rust `&'static [u8]` literals)
+        std::string l((const char *)label, label_len);
+        if (l.find('\0') != std::string::npos) return BPG_EINVAL;
+        rcs->cs->challenge_scalar(l).to_bytes(out32);
+        return BPG_OK;
+    });
+}
+
 int bpg_cs_export_terms(const bpg_cs *cs, uint64_t *vars, uint8_t *coeffs32, uint32_t *constraint, size_t cap, size_t *n_terms) {
     if (!cs || !n_terms) return BPG_EINVAL;
     const ConstraintStore &st = cs->cs->store();

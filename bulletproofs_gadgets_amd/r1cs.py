@@ -189,6 +189,29 @@ class _CS:
         v, c, n = LinearCombination.of(lc).marshal()
         check(lib().bpg_cs_constrain(self._cs, v, c, n))
 
+    def specify_randomized_constraints(self, callback):
+        """RandomizableConstraintSystem::specify_randomized_constraints: `callback(rcs)` runs inside prove() /
+        verify(), after the first-phase commitments; rcs offers challenge_scalar(label) beside multiply /
+        allocate_multiplier / constrain.  An exception raised by the callback is re-raised by prove / verify."""
+        owner = self
+
+        def tramp(_user, rcs_ptr):
+            try:
+                callback(_RandomizedCS(rcs_ptr))
+                return 0
+            except BaseException as e:          # never unwind through the C frames
+                owner._cb_error = e
+                return _native.EINVAL
+
+        fn = _native.RANDOMIZED_FN(tramp)
+        self.__dict__.setdefault("_keep", []).append(fn)     # the library holds the pointer until prove / verify
+        check(lib().bpg_cs_specify_randomized_constraints(self._cs, fn, None))
+
+    def _raise_callback_error(self):
+        e = self.__dict__.pop("_cb_error", None)
+        if e is not None:
+            raise e
+
     def export_terms(self):
         """[(kind, index, coeff, constraint)] for every linear-combination term captured so far (bpg_cs_export_terms)"""
         n = ctypes.c_size_t()
@@ -198,6 +221,21 @@ class _CS:
         check(lib().bpg_cs_export_terms(self._cs, vars_, coeffs, q, k, ctypes.byref(n)))
         return [(vars_[t] >> 32, vars_[t] & 0xffffffff, int.from_bytes(coeffs.raw[32 * t:32 * t + 32], "little"), q[t])
                 for t in range(n.value)]
+
+
+class _RandomizedCS(_CS):
+    """the `rcs` handed to a randomized-constraints callback (valid during that call only)"""
+
+    def __init__(self, ptr):
+        self._cs = ptr
+
+    def challenge_scalar(self, label):
+        out = ctypes.create_string_buffer(32)
+        check(lib().bpg_cs_challenge_scalar(self._cs, label, len(label), out))
+        return int.from_bytes(out.raw, "little")
+
+    def specify_randomized_constraints(self, callback):
+        raise ValueError("already in the randomization phase")
 
 
 class Prover(_CS):
@@ -237,7 +275,9 @@ class Prover(_CS):
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap)
         n = ctypes.c_size_t()
-        check(lib().bpg_prover_prove(self._h, rng.cb, None, out, cap, ctypes.byref(n)))
+        rc = lib().bpg_prover_prove(self._h, rng.cb, None, out, cap, ctypes.byref(n))
+        self._raise_callback_error()
+        check(rc)
         rng.check()
         return Proof(out.raw[:n.value])
 
@@ -251,7 +291,10 @@ class Prover(_CS):
         out = ctypes.create_string_buffer(cap * max(k, 1))
         lens = (ctypes.c_size_t * max(k, 1))()
         hs = (ctypes.c_void_p * max(k, 1))(*[p._h for p in provers])
-        check(lib().bpg_prover_prove_many(hs, k, rng.cb, None, out, cap, lens))
+        rc = lib().bpg_prover_prove_many(hs, k, rng.cb, None, out, cap, lens)
+        for p in provers:
+            p._raise_callback_error()
+        check(rc)
         rng.check()
         return [Proof(out.raw[j * cap:j * cap + lens[j]]) for j in range(k)]
 
@@ -298,6 +341,7 @@ class Verifier(_CS):
         raw = proof.to_bytes() if hasattr(proof, "to_bytes") else bytes(proof)
         rng = _Rng(external_rng32)
         rc = lib().bpg_verifier_verify(self._h, bp_gens._h, raw, len(raw), rng.cb, None)
+        self._raise_callback_error()
         rng.check()
         if rc == _native.EVERIFY:
             raise VerificationError()
@@ -332,6 +376,8 @@ def verify_batch(verifiers, proofs, bp_gens, external_rng=None):
     lens = (ctypes.c_size_t * max(k, 1))(*[len(r) for r in raws])
     rng = _Rng(external_rng)
     rc = lib().bpg_verifier_verify_batch(vs, ps, lens, k, bp_gens._h, rng.cb, None)
+    for v in verifiers:
+        v._raise_callback_error()
     rng.check()
     if rc == _native.EVERIFY:
         raise VerificationError()

@@ -230,6 +230,20 @@ int bpg_cs_multiply(bpg_cs *cs, const uint64_t *lvars, const uint8_t *lcoeffs, s
 int bpg_cs_allocate_multiplier(bpg_cs *cs, const uint8_t *left32, const uint8_t *right32, uint64_t out[3]);
 int bpg_cs_constrain(bpg_cs *cs, const uint64_t *vars, const uint8_t *coeffs, size_t n);
 
+/* RandomizableConstraintSystem::specify_randomized_constraints(|rcs| { ... }) and
+ * RandomizedConstraintSystem::challenge_scalar(label) -- bulletproofs::r1cs with feature yoloproofs (ref: Cargo.toml:18);
+ * the reference imports RandomizedConstraintSystem at src/gadgets/point/ristretto_point.rs:3 and none of its gadgets
+ * registers a randomized constraint, so nothing in the reference exercises this pair.  `callback` runs
+ * later, inside bpg_prover_prove / bpg_verifier_verify, once the first-phase commitments A_I1, A_O1, S1 are in the
+ * transcript; `rcs` is valid only during that call and accepts bpg_cs_challenge_scalar, bpg_cs_multiply,
+ * bpg_cs_allocate_multiplier, bpg_cs_constrain and the gadget functions.  Multipliers allocated there form the second
+ * phase (A_I2, A_O2, S2; proof version byte 1).  The callback returns 0 or a BPG_E* code, which prove / verify then
+ * return.  bpg_cs_challenge_scalar outside a callback is BPG_EINVAL.  Provers with randomized constraints passed to
+ * bpg_prover_prove_many are proved one at a time. */
+typedef int (*bpg_randomized_fn)(void *user, bpg_cs *rcs);
+int bpg_cs_specify_randomized_constraints(bpg_cs *cs, bpg_randomized_fn callback, void *user);
+int bpg_cs_challenge_scalar(bpg_cs *rcs, const uint8_t *label, size_t label_len, uint8_t out32[32]);
+
 /* The constraint system as captured so far, one record per linear-combination term in capture order:
  * vars[t] (packed as above), coeffs32[t] (32 bytes), constraint[t] (index of the constrain() call, counting the two
  * implicit ones of each multiply()).  *n_terms is always set; BPG_EINVAL if cap is too small.  No counterpart in

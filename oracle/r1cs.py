@@ -178,6 +178,9 @@ class Transcript:
     def r1cs_1phase_domain_sep(self):
         self.append_message(b"dom-sep", b"r1cs-1phase")
 
+    def r1cs_2phase_domain_sep(self):
+        self.append_message(b"dom-sep", b"r1cs-2phase")
+
     def innerproduct_domain_sep(self, n):
         self.append_message(b"dom-sep", b"ipp v1")
         self.append_u64(b"n", n)
@@ -280,6 +283,36 @@ class R1CSProof:
 # ----------------------------------------------------------------------------- constraint systems
 
 class _CS:
+    """ConstraintSystem + RandomizableConstraintSystem + RandomizedConstraintSystem (bulletproofs::r1cs, feature
+    yoloproofs).  `RandomizedConstraintSystem` is imported by the reference at src/gadgets/point/ristretto_point.rs:3;
+    none of its gadgets registers a randomized constraint, so this half of the protocol is exercised by a
+    shuffle-style circuit of the tests only."""
+    _phase2 = False
+
+    def specify_randomized_constraints(self, callback):
+        """callback(cs) runs after the first-phase commitments A_I1, A_O1, S1 are in the transcript; it may draw
+        challenges (cs.challenge_scalar), allocate multipliers and add constraints"""
+        self.deferred.append(callback)
+
+    def challenge_scalar(self, label):
+        """RandomizedConstraintSystem::challenge_scalar: only inside a randomized-constraints callback"""
+        if not self._phase2:
+            raise R1CSError("challenge_scalar outside the randomization phase")
+        return self.transcript.challenge_scalar(label)
+
+    def _create_randomized_constraints(self):
+        if not self.deferred:
+            self.transcript.r1cs_1phase_domain_sep()
+            return
+        self.transcript.r1cs_2phase_domain_sep()
+        callbacks, self.deferred = self.deferred, []
+        self._phase2 = True
+        try:
+            for cb in callbacks:
+                cb(self)
+        finally:
+            self._phase2 = False
+
     def multiply(self, left, right):
         raise NotImplementedError
 
@@ -314,6 +347,7 @@ class Prover(_CS):
         self.orc, self.pc_gens, self.transcript = orc, pc_gens, transcript
         transcript.r1cs_domain_sep()
         self.constraints, self.a_L, self.a_R, self.a_O, self.v, self.v_blinding = [], [], [], [], [], []
+        self.deferred = []
 
     def commit(self, v, v_blinding):
         i = len(self.v)
@@ -358,31 +392,49 @@ class Prover(_CS):
         orc, tr = self.orc, self.transcript
         tr.append_u64(b"m", len(self.v))
         rng = tr.build_rng(self.v_blinding, external_rng32)
-        n1 = n = len(self.a_L)
+        n1 = len(self.a_L)
         if bp_gens.gens_capacity < n1:
             raise InvalidGeneratorsLength()
-        i_bl, o_bl, s_bl = rng.scalar(), rng.scalar(), rng.scalar()
-        s_L = rng.scalars(n1)
-        s_R = rng.scalars(n1)
-        Gn, Hn = orc.slice(bp_gens.G, 0, n), orc.slice(bp_gens.H, 0, n)
-        bgh, _ = orc.concat((self.pc_gens.B_blinding, 1), (Gn, n), (Hn, n))
-        bg, _ = orc.concat((self.pc_gens.B_blinding, 1), (Gn, n))
+        i_bl1, o_bl1, s_bl1 = rng.scalar(), rng.scalar(), rng.scalar()
+        s_L1 = rng.scalars(n1)
+        s_R1 = rng.scalars(n1)
         CT = binding.SCHED_STRAUS_CT
-        A_I1 = orc.msm(sc(i_bl) + sc_join(self.a_L) + sc_join(self.a_R), bgh, 2 * n + 1, CT)
-        A_O1 = orc.msm(sc(o_bl) + sc_join(self.a_O), bg, n + 1, CT)
-        S1 = orc.msm(sc(s_bl) + sc_join(s_L) + sc_join(s_R), bgh, 2 * n + 1, CT)
+
+        def commit3(lo, hi, bl, s_L, s_R):
+            """A_I, A_O, S over the multipliers [lo, hi) and the generators G[lo..hi), H[lo..hi)"""
+            k = hi - lo
+            Gk, Hk = orc.slice(bp_gens.G, lo, k), orc.slice(bp_gens.H, lo, k)
+            bgh, _ = orc.concat((self.pc_gens.B_blinding, 1), (Gk, k), (Hk, k))
+            bg, _ = orc.concat((self.pc_gens.B_blinding, 1), (Gk, k))
+            A_I = orc.msm(sc(bl[0]) + sc_join(self.a_L[lo:hi]) + sc_join(self.a_R[lo:hi]), bgh, 2 * k + 1, CT)
+            A_O = orc.msm(sc(bl[1]) + sc_join(self.a_O[lo:hi]), bg, k + 1, CT)
+            S = orc.msm(sc(bl[2]) + sc_join(s_L) + sc_join(s_R), bgh, 2 * k + 1, CT)
+            return A_I, A_O, S
+        A_I1, A_O1, S1 = commit3(0, n1, (i_bl1, o_bl1, s_bl1), s_L1, s_R1)
         tr.append_point(b"A_I1", A_I1)
         tr.append_point(b"A_O1", A_O1)
         tr.append_point(b"S1", S1)
-        tr.r1cs_1phase_domain_sep()           # no randomized constraints in the reference's gadgets
+        self._create_randomized_constraints()     # dom-sep r1cs-1phase, or r1cs-2phase + the deferred callbacks
+        n = len(self.a_L)
+        n2 = n - n1
         padded_n = 1 if n == 0 else 1 << (n - 1).bit_length()
         pad = padded_n - n
         if bp_gens.gens_capacity < padded_n:
             raise InvalidGeneratorsLength()
         ident = bytes(32)
-        tr.append_point(b"A_I2", ident)
-        tr.append_point(b"A_O2", ident)
-        tr.append_point(b"S2", ident)
+        if n2 > 0:
+            i_bl2, o_bl2, s_bl2 = rng.scalar(), rng.scalar(), rng.scalar()
+            s_L2 = rng.scalars(n2)
+            s_R2 = rng.scalars(n2)
+            A_I2, A_O2, S2 = commit3(n1, n, (i_bl2, o_bl2, s_bl2), s_L2, s_R2)
+        else:
+            i_bl2 = o_bl2 = s_bl2 = 0
+            s_L2, s_R2 = [], []
+            A_I2 = A_O2 = S2 = ident
+        s_L, s_R = s_L1 + s_L2, s_R1 + s_R2
+        tr.append_point(b"A_I2", A_I2)
+        tr.append_point(b"A_O2", A_O2)
+        tr.append_point(b"S2", S2)
         y = tr.challenge_scalar(b"y")
         z = tr.challenge_scalar(b"z")
         wL, wR, wO, wV, _ = self._flatten(z, n, len(self.v), False)
@@ -425,7 +477,8 @@ class Prover(_CS):
         for i in range(n, padded_n):
             r_vec[i] = (-exp_y) % L
             exp_y = exp_y * y % L
-        e_blinding = x * (i_bl + x * (o_bl + x * s_bl)) % L     # second-phase blindings are zero
+        i_bl, o_bl, s_bl = (i_bl1 + u * i_bl2) % L, (o_bl1 + u * o_bl2) % L, (s_bl1 + u * s_bl2) % L
+        e_blinding = x * (i_bl + x * (o_bl + x * s_bl)) % L
         tr.append_scalar(b"t_x", t_x)
         tr.append_scalar(b"t_x_blinding", t_x_blinding)
         tr.append_scalar(b"e_blinding", e_blinding)
@@ -433,11 +486,11 @@ class Prover(_CS):
         Q = orc.ge_array(1)
         wq = ctypes.create_string_buffer(sc(w))
         orc.lib.msm_straus_ct(Q, wq, self.pc_gens.B, ctypes.c_size_t(1))          # Q = w * B
-        G_factors = [1] * n1 + [u] * pad
+        G_factors = [1] * n1 + [u] * (n2 + pad)
         H_factors = [exp_y_inv[i] * G_factors[i] % L for i in range(padded_n)]
         ipp = ipp_create(orc, tr, Q, G_factors, H_factors, orc.slice(bp_gens.G, 0, padded_n),
                          orc.slice(bp_gens.H, 0, padded_n), l_vec, r_vec)
-        return R1CSProof(A_I1=A_I1, A_O1=A_O1, S1=S1, A_I2=ident, A_O2=ident, S2=ident, T_1=T_1, T_3=T_3, T_4=T_4,
+        return R1CSProof(A_I1=A_I1, A_O1=A_O1, S1=S1, A_I2=A_I2, A_O2=A_O2, S2=S2, T_1=T_1, T_3=T_3, T_4=T_4,
                          T_5=T_5, T_6=T_6, t_x=t_x, t_x_blinding=t_x_blinding, e_blinding=e_blinding, ipp=ipp)
 
 
@@ -514,6 +567,7 @@ class Verifier(_CS):
         self.orc, self.transcript = orc, transcript
         transcript.r1cs_domain_sep()
         self.constraints, self.num_vars, self.V = [], 0, []
+        self.deferred = []
 
     def commit(self, V32):
         i = len(self.V)
@@ -538,11 +592,13 @@ class Verifier(_CS):
     def verify(self, proof, pc_gens, bp_gens, external_rng32=bytes(32)):
         orc, tr = self.orc, self.transcript
         tr.append_u64(b"m", len(self.V))
-        n1 = n = self.num_vars
+        n1 = self.num_vars
         tr.validate_and_append_point(b"A_I1", proof.A_I1)
         tr.validate_and_append_point(b"A_O1", proof.A_O1)
         tr.validate_and_append_point(b"S1", proof.S1)
-        tr.r1cs_1phase_domain_sep()
+        self._create_randomized_constraints()
+        n = self.num_vars
+        n2 = n - n1
         padded_n = 1 if n == 0 else 1 << (n - 1).bit_length()
         pad = padded_n - n
         if bp_gens.gens_capacity < padded_n:
@@ -569,7 +625,7 @@ class Verifier(_CS):
             y_inv_vec[i] = y_inv_vec[i - 1] * y_inv % L
         yneg_wR = [wR[i] * y_inv_vec[i] % L for i in range(n)] + [0] * pad
         delta = sum(yneg_wR[i] * wL[i] for i in range(n)) % L
-        u_for = [1] * n1 + [u] * pad
+        u_for = [1] * n1 + [u] * (n2 + pad)
         g_scalars = [u_for[i] * (x * yneg_wR[i] - a * s[i]) % L for i in range(padded_n)]
         wLp, wOp = wL + [0] * pad, wO + [0] * pad
         h_scalars = [u_for[i] * (y_inv_vec[i] * (x * wLp[i] + wOp[i] - b * s[padded_n - 1 - i]) - 1) % L for i in range(padded_n)]

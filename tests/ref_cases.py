@@ -214,3 +214,59 @@ def scalar_mul_roundtrip(be, base, bits, expected, rng=None, cap=None):
         q2.equal(be.EdwardsGadget.from_point(expected), v)
         v.verify(proof, be.pc_gens, bp, rng.fill_bytes(32))
     return _ok(verify, be), proof
+
+
+# ---- randomized (two-phase) constraints.  The reference enables them (Cargo.toml:18 `yoloproofs`,
+# ristretto_point.rs:3 imports RandomizedConstraintSystem) and registers none, so it has no test to restate; the case
+# below is the k-shuffle the bulletproofs r1cs documentation builds on specify_randomized_constraints:
+# prod (x_i - z) == prod (y_i - z) for a challenge z drawn after the first-phase commitments.
+def shuffle_gadget(cs, x, y):
+    k = len(x)
+    assert len(y) == k
+    if k == 1:
+        cs.constrain(y[0] - x[0])
+        return
+
+    def randomized(rcs):
+        z = rcs.challenge_scalar(b"shuffle challenge")
+
+        def product(v):
+            _, _, out = rcs.multiply(v[k - 1] - z, v[k - 2] - z)
+            for i in reversed(range(k - 2)):
+                _, _, out = rcs.multiply(out + 0, v[i] - z)
+            return out
+        rcs.constrain(product(x) - product(y))
+    cs.specify_randomized_constraints(randomized)
+
+
+def shuffle_roundtrip(be, inputs, outputs, first_phase_squares=0, rng=None, cap=64):
+    """Proves that `outputs` is a permutation of `inputs` (both committed).  first_phase_squares > 0 also allocates
+    that many first-phase multipliers (x_0 * x_0 = committed square), so that a proof carries both phases."""
+    rng = rng or SeededRng(b"shuffle")
+    bp = be.bp_gens(cap)
+    k = len(inputs)
+    prover = be.Prover(be.Transcript(b"ShuffleProof"))
+    comms, xs, ys = [], [], []
+    for v in list(inputs) + list(outputs):
+        V, var = prover.commit(v, rng.scalar())
+        comms.append(V)
+        (xs if len(xs) < k else ys).append(var)
+    sq_comms = []
+    for _ in range(first_phase_squares):
+        V, sq = prover.commit(inputs[0] * inputs[0], rng.scalar())
+        sq_comms.append(V)
+        _, _, o = prover.multiply(xs[0] + 0, xs[0] + 0)
+        prover.constrain(o - sq)
+    shuffle_gadget(prover, xs, ys)
+    proof = prover.prove(bp, rng.fill_bytes(32))
+
+    def verify():
+        v = be.Verifier(be.Transcript(b"ShuffleProof"))
+        vv = [v.commit(c) for c in comms]
+        for c in sq_comms:
+            sq = v.commit(c)
+            _, _, o = v.multiply(vv[0] + 0, vv[0] + 0)
+            v.constrain(o - sq)
+        shuffle_gadget(v, vv[:k], vv[k:])
+        v.verify(proof, be.pc_gens, bp, rng.fill_bytes(32))
+    return _ok(verify, be), proof

@@ -165,3 +165,34 @@ def test_multiplier_counts_match_survey(be, rnd):
     bits = [v.commit(bytes(32)) for _ in range(3)]
     E.scalar_mul(g, bits, v)
     assert v.num_vars == 27 * 3
+
+
+def test_randomized_constraints_shuffle(be, rnd):
+    """SURVEY 8f4 (two-phase constraints; parity unpinned: the reference registers none, so it holds no vector).
+    Checks the protocol's own properties: completeness, soundness on a non-permutation, the version-1 encoding."""
+    xs = [rnd.randrange(L) for _ in range(5)]
+    perm = xs[:]
+    rnd.shuffle(perm)
+    ok, proof = rc.shuffle_roundtrip(be, xs, perm)
+    assert ok
+    raw = proof.to_bytes()
+    assert raw[0] == 1 and len(raw) == 1 + 14 * 32 + 2 * 3 * 32 + 64      # two-phase: A_I2, A_O2, S2 present; n = 8
+    assert R.R1CSProof.from_bytes(raw).to_bytes() == raw
+    bad = perm[:]
+    bad[2] = (bad[2] + 1) % L
+    assert not rc.shuffle_roundtrip(be, xs, bad)[0]
+    # both phases populated: 3 first-phase multipliers, 2 * (k - 1) second-phase ones
+    ok, proof = rc.shuffle_roundtrip(be, xs, perm, first_phase_squares=3)
+    assert ok and proof.to_bytes()[0] == 1
+    assert not rc.shuffle_roundtrip(be, xs, bad, first_phase_squares=3)[0]
+    # k = 1 registers no callback: a one-phase proof
+    ok, proof = rc.shuffle_roundtrip(be, xs[:1], xs[:1])
+    assert ok and proof.to_bytes()[0] == 0
+    # k = 2: one multiplier per side
+    assert rc.shuffle_roundtrip(be, xs[:2], xs[1::-1])[0]
+
+
+def test_challenge_scalar_outside_the_randomization_phase(be):
+    p = be.Prover(be.Transcript(b"x"))
+    with pytest.raises(R.R1CSError):
+        p.challenge_scalar(b"c")
