@@ -31,9 +31,12 @@ os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("BPG_BENCH_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Measured on MI355X by tools/ubench (profiles/r01_ubench.json): sustained v_mad_u64_u32 issue, all CUs,
-# eight independent chains per lane with distinct multiplicands (the guide has no integer-multiply figure).
-VMAD_PEAK_GMACS = 28744.0
+# v_mad_u64_u32 issues once per 4 cycles per SIMD (64 lanes): 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 = 39.3 T MAC/s,
+# the same rate as the guide's fp64 FMA figure.  tools/ubench (profiles/r02_ubench.json, kernels of 7 ms) measures
+# 37.1 T/s for it on MI355X, with its anchors at 73.0 of 78.6 T simple int32 ops/s and 36.6 of 39.3 T fp64 FMA/s;
+# the nominal figure is the denominator (round 1 used a figure measured with 75-us kernels: 28.7 T/s, too low).
+VMAD_PEAK_GMACS = 39321.6
+VMAD_MEASURED_GMACS = 37062.1
 # HBM-side bytes of one k_accumulate launch at 2^20 points, from rocprofv3 PMC passes (FETCH_SIZE doubled per the
 # guide's gfx950 correction, WRITE_SIZE as read): profiles/r01_pmc_*.csv.  bench.py cannot collect PMC itself.
 ACC_TRAFFIC_BYTES_2_20 = 3.04e9          # 2 x 1.44 GB fetched + 0.16 GB written (gathered table lines: every point is read once per window)
@@ -43,14 +46,24 @@ MAC_PER_POINT_MSM = 8640                     # W(2^20, 16), whole MSM
 BYTES_PER_POINT = 128                        # 32 B scalar + 96 B affine-Niels point
 
 
+def host_cores():
+    """the cores this process may use (the GPU box gives one GPU's job 16 of the machine's cores)"""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, int(os.environ.get("BPG_BENCH_CPU_CORES", os.environ.get("OMP_NUM_THREADS", "16")))))
+
+
 def cpu_baseline(ctx, pts, scalars, sample_n):
-    """Oracle (CPU port of dalek's Pippenger) on the first sample_n points; returns (points/s, ok)."""
+    """Oracle (CPU port of dalek's Pippenger) on the first sample_n points: one MSM on one core, then one MSM per
+    core on every core at once (the C call releases the GIL).  Returns (points/s one core, ok, s, points/s all cores, cores, s)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding
     orc = binding.load()
     enc = pts.compress(0, sample_n)            # same points as the GPU table, as ristretto bytes
     arr = orc.ge_array(sample_n)
-    workers = min(16, os.cpu_count() or 1)
+    workers = host_cores()
     chunk = (sample_n + workers - 1) // workers
 
     def dec(k):                                # setup (untimed): decode points for the CPU
@@ -65,7 +78,25 @@ def cpu_baseline(ctx, pts, scalars, sample_n):
     want = orc.msm(sc, arr, sample_n, binding.SCHED_PIPPENGER)
     dt = time.perf_counter() - t0
     got = ctx.msm(pts, sc)                     # pts[0:sample_n] with the same scalars
-    return sample_n / dt, got == want, dt
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex:    # the same MSM once per core, all cores busy
+        res = list(ex.map(lambda _: orc.msm(sc, arr, sample_n, binding.SCHED_PIPPENGER), range(workers)))
+    dt_all = time.perf_counter() - t0
+    return sample_n / dt, got == want and all(r == want for r in res), dt, workers * sample_n / dt_all, workers, dt_all
+
+
+def proof_algorithmic_macs(lg):
+    """Multiply-accumulates of ONE proof at 2^lg multipliers (padded), bucket accumulation only, for the schedule
+    this library runs: every multiscalar multiplication priced at the canonical window for
+    these sizes, c = 13 -> 20 windows x 504 MAC per point (W(2^16, 13) without the bucket reduction).
+    Points: A_I, A_O, S = 5n + 3; T_1..T_6 = 10; inner-product rounds before the generators are folded
+    (k0 = lg - 11 of them) read all 2n original generators each; the fold itself passes the 2n generators once;
+    the remaining rounds read 2 n_k folded generators each.  The reference's schedule (dalek: Straus MSMs and a
+    2-term multiplication per folded generator per round) costs about 2.9e10 MAC at lg = 16."""
+    n = 1 << lg
+    k0 = lg - 11 if lg >= 12 else 0
+    pts = (5 * n + 3) + 10 + 2 * n * k0 + (2 * n if k0 else 0) + sum(2 * (n >> k) + 2 for k in range(k0, lg))
+    return pts * 20 * 504, pts
 
 
 PROOF_BITS = 2427        # SURVEY.md 8(d) cfg3: 27 * 2427 + 4 = 65 533 multipliers -> n+ = 2^16
@@ -183,6 +214,24 @@ def proof_cpu_baseline(nbits=PROOF_BITS):
     return time.perf_counter() - t0, proof.to_bytes()
 
 
+def proof_cpu_baseline_all_cores(cores, nbits=PROOF_BITS):
+    """one oracle proof per core on `cores` cores at once: child processes that never touch the GPU
+    (python -m tools.cpu_proof_worker).  Returns (proofs/s, wall seconds, fraction of a worker's time spent inside
+    the oracle's C library -- the rest is Python orchestration)."""
+    import subprocess
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-m", "tools.cpu_proof_worker", str(nbits)], cwd=ROOT, stdout=subprocess.PIPE,
+                              env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1"))
+             for _ in range(cores)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    wall = time.perf_counter() - t0
+    recs = [json.loads(o.decode().strip().splitlines()[-1]) for o, p in zip(outs, procs) if p.returncode == 0 and o.strip()]
+    if len(recs) != cores:
+        raise RuntimeError("cpu proof workers failed: %d of %d" % (cores - len(recs), cores))
+    span = max(r["end"] for r in recs) - min(r["start"] for r in recs)      # excludes interpreter start-up
+    return cores / span, wall, sum(r["c_frac"] for r in recs) / cores, len({r["sha256"] for r in recs}) == 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +329,78 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- one MSM at a time: latency (submit -> result on the host), scalars resident / uploaded by the call
+    def median(xs):
+        xs = sorted(xs)
+        return xs[len(xs) // 2]
+    lat_res, lat_host = [], []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        finish(ctx.msm_submit(pts, d_sc.ptr, n))
+        lat_res.append((time.perf_counter() - t0) * 1e3)
+    if world == 1:
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.msm(pts, sc)
+            lat_host.append((time.perf_counter() - t0) * 1e3)
+    # ---- PCIe-inclusive rate: every step uploads its 32 MB of scalars from host memory (bpg_msm, what a drop-in
+    #      for multiscalar_mul(host scalars, resident points) does), `in_flight` host threads each on its own lane
+    pcie = None
+    if world == 1:
+        import threading
+        per = max(2, args.steps // args.in_flight)
+
+        def up_worker(k):
+            for _ in range(k):
+                ctx.msm(pts, sc)
+        for k in (1, per):
+            th = [threading.Thread(target=up_worker, args=(k,)) for _ in range(args.in_flight)]
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            [t.start() for t in th]
+            [t.join() for t in th]
+            dt_up = time.perf_counter() - t0
+        pcie = {"value": args.in_flight * per * n / dt_up, "unit": "points/s", "host_threads": args.in_flight, "msms": args.in_flight * per,
+                "note": "bpg_msm: scalars in pageable host memory, uploaded by every call (33.5 MB per MSM); never `value`"}
+
+    # ---- strong scaling: ONE MSM of 2^20 (and of 2^22) points split N ways by point range; `value` above is the weak figure
+    strong = {}
+    for logt in (20, 22):
+        nl = (1 << logt) // world
+        if world == 1 and logt == args.logn:
+            strong["2^%d" % logt] = {"points_per_s": None, "note": "N = 1: the headline configuration itself"}
+            continue
+        try:
+            pts_s = ctx.points_from_uniform(synth.uniform_bytes(nl, tag=b"S%d/%d/%d" % (logt, world, rank)))
+            sc_s = synth.scalars(nl, tag=b"t%d/%d/%d" % (logt, world, rank))
+            d_s = ctx.alloc(len(sc_s)).upload(sc_s)
+
+            def run_s(steps):
+                inflight, out = [], None
+                for _ in range(steps):
+                    inflight.append(ctx.msm_submit(pts_s, d_s.ptr, nl))
+                    if len(inflight) == args.in_flight:
+                        out = finish(inflight.pop(0))
+                for j in inflight:
+                    out = finish(j)
+                return out
+            run_s(max(2, args.warmup))
+            barrier()
+            t0 = time.perf_counter()
+            run_s(args.steps)
+            barrier()
+            dts = time.perf_counter() - t0
+            if world > 1:
+                tm = torch.tensor([dts], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dts = float(tm.item())
+            strong["2^%d" % logt] = {"points_per_s": nl * world * args.steps / dts, "ms_per_msm": dts / args.steps * 1e3,
+                                     "points_per_gpu": nl, "scaling": "strong"}
+            d_s.free()
+            pts_s.free()
+        except Exception as e:  # noqa: BLE001
+            strong["2^%d" % logt] = {"error": repr(e)}
+
     # ---- secondary metric: R1CS proofs/s at 2^16 multipliers (independent proofs; ranks share nothing)
     proofs = None
     if not args.no_proofs:
@@ -327,6 +448,15 @@ def main():
                    "ranks": world, "gens_setup_s": round(gens_s, 3), "capture_commit_s": round(best[0], 3), "prove_s": round(best[1], 4),
                    "verify_s": round(best[2], 4), "prover_timing_ms": {k: round(v, 1) for k, v in best[3].items()},
                    "proof_sha256": hashlib.sha256(proof.to_bytes()).hexdigest()}
+            # what every rank repeats whatever N is: circuit capture + commitments, and the blinding draw (one
+            # sequential Keccak chain; bit-exactness fixes its order).  The MSMs are what the ranks split.
+            serial = best[0] + best[3].get("rng_ms", 0.0) / 1e3
+            total = best[0] + best[1]
+            big["host_serial_s"] = round(serial, 4)
+            big["amdahl_bound"] = {"total_s_at_this_n": round(total, 4),
+                                   "speedup_limit_8_ranks": round(total / (serial + (total - serial) / 8), 2),
+                                   "note": "capture + commit and the blinding RNG run on every rank; only the remainder (MSMs, "
+                                           "scalar-vector kernels) can shrink with N"}
         except Exception as e:  # noqa: BLE001  (the headline line must survive a failure here)
             big = {"error": repr(e)}
     # ---- BASELINE configs[4]: 4096 Ristretto-gadget proofs per GPU, verified by one combined MSM (no collective)
@@ -377,6 +507,8 @@ def main():
                        "in_flight": args.in_flight, "table_build_s": round(table_s, 4), "result": result.hex()},
             "roofline": {"bound": "valu_int32 (v_mad_u64_u32 issue)", "kernel": "k_accumulate",
                          "achieved": achieved, "peak": VMAD_PEAK_GMACS, "unit": "GMAC/s", "frac": achieved / VMAD_PEAK_GMACS,
+                         "peak_measured": VMAD_MEASURED_GMACS, "frac_of_measured": achieved / VMAD_MEASURED_GMACS,
+                         "peak_note": "256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32; tools/ubench measures 37.1 T/s (profiles/r02_ubench.json)",
                          "kernel_avg_us": acc, "kernel_alone_us": min(alone_us), "frac_alone": MAC_PER_POINT_ACCUMULATE * n / (min(alone_us) * 1e-6) / 1e9 / VMAD_PEAK_GMACS,
                          "note": "kernel_avg_us: timed region, %d MSMs in flight (their accumulate passes run one after another, the other kernels overlap them); kernel_alone_us: the same kernel with the GPU to itself" % args.in_flight,
                          "algorithmic_mac_per_point": MAC_PER_POINT_ACCUMULATE,
@@ -384,20 +516,50 @@ def main():
                          "hbm_algorithmic_GBps": BYTES_PER_POINT * n / (acc * 1e-6) / 1e9, "hbm_peak_GBps": 8000.0,
                          "traffic": ACC_TRAFFIC_BYTES_2_20 if args.logn == 20 else None},
         }
+        line["latency_ms"] = {"msm_resident_scalars": median(lat_res), "msm_host_scalars": median(lat_host) if lat_host else None,
+                              "note": "one 2^%d-point MSM with the GPU to itself, submit -> 32 result bytes on the host" % args.logn}
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
+        line["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             sample = n                      # the whole workload: ~3 s of one core at 2^20
-            v, ok, cpu_s = cpu_baseline(ctx, pts, sc, sample)
-            line["cpu_baseline"] = {"value": v, "unit": "points/s", "cores": 1, "kind": "port",
-                                    "sample": "oracle msm_pippenger_vt (dalek vartime Pippenger, w=8) on the first 2^%d points, %.1f s"
-                                              % (sample.bit_length() - 1, cpu_s),
+            v, ok, cpu_s, v_all, cores, cpu_all_s = cpu_baseline(ctx, pts, sc, sample)
+            line["cpu_baseline"] = {"value": v_all, "unit": "points/s", "cores": cores, "kind": "port",
+                                    "sample": "oracle msm_pippenger_vt (dalek vartime Pippenger, w=8) on the 2^%d points of the step, one "
+                                              "such MSM per core on %d cores at once, %.1f s" % (sample.bit_length() - 1, cores, cpu_all_s),
+                                    "single_core": {"value": v, "cores": 1, "seconds": round(cpu_s, 2)},
                                     "parity_with_gpu": bool(ok)}
         if proofs is not None:
+            lgp = (27 * PROOF_BITS + 3).bit_length()
+            macs, ppts = proof_algorithmic_macs(lgp)
+            ach = proofs["prove"] * macs / 1e9
+            proofs["roofline"] = {"bound": "valu_int32 (v_mad_u64_u32 issue)", "achieved": ach, "peak": VMAD_PEAK_GMACS * world, "unit": "GMAC/s",
+                                  "frac": ach / (VMAD_PEAK_GMACS * world), "algorithmic_mac_per_proof": macs, "msm_points_per_proof": ppts,
+                                  "reference_schedule_mac_per_proof": 2.88e10,
+                                  "note": "whole prove() calls per second (host work included) x the bucket-accumulation MACs of the "
+                                          "schedule this library runs (fold-free first rounds, one fold, c = 13: 20 windows x 504 MAC per "
+                                          "point); the reference's own schedule would need 2.9e10 MAC per proof"}
             if world == 1 and not args.no_cpu_baseline:
                 cpu_s, cpu_proof = proof_cpu_baseline()
+                cores = host_cores()
                 proofs["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
                                           "sample": "oracle prover (Straus-CT MSMs, per-element generator folds), the same "
                                                     "statement, 1 proof, %.1f s" % cpu_s,
                                           "proof_bytes_equal_gpu": cpu_proof == first_proof.to_bytes()}
+                try:
+                    v_all, wall, c_frac, same = proof_cpu_baseline_all_cores(cores)
+                    proofs["cpu_baseline"].update({
+                        "value": v_all, "cores": cores,
+                        "sample": "oracle prover (Straus-CT MSMs, per-element generator folds), the same statement, one proof per "
+                                  "core on %d cores at once, %.1f s wall" % (cores, wall),
+                        "single_core": {"value": 1.0 / cpu_s, "cores": 1, "seconds": round(cpu_s, 1)},
+                        "time_inside_the_c_library": round(c_frac, 3),
+                        "note": "orchestrated from Python (oracle/r1cs.py); time_inside_the_c_library is the share of a worker's "
+                                "proving time spent in oracle/*.c (MSMs, folds, scalar vectors), the rest is interpreter overhead "
+                                "a C or Rust prover would not pay",
+                        "workers_agree": bool(same)})
+                except Exception as e:  # noqa: BLE001
+                    proofs["cpu_baseline"]["all_cores_error"] = repr(e)
             line["secondary"] = proofs
         if big is not None:
             line["proof_2_20"] = big
