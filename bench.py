@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--proofs-per-call", type=int, default=8, help="statements per bpg_prover_prove_many call (1: plain prove calls)")
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency, PCIe-inclusive and strong-scaling legs (profiling runs)")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("BPG_BENCH_IN_FLIGHT", "4")),
                     help="MSM jobs submitted before the oldest is waited for (each on its own stream)")
     args = ap.parse_args()
@@ -334,11 +335,11 @@ def main():
         xs = sorted(xs)
         return xs[len(xs) // 2]
     lat_res, lat_host = [], []
-    for _ in range(7):
+    for _ in range(0 if args.no_extras else 7):
         t0 = time.perf_counter()
         finish(ctx.msm_submit(pts, d_sc.ptr, n))
         lat_res.append((time.perf_counter() - t0) * 1e3)
-    if world == 1:
+    if world == 1 and not args.no_extras:
         for _ in range(5):
             t0 = time.perf_counter()
             ctx.msm(pts, sc)
@@ -346,7 +347,7 @@ def main():
     # ---- PCIe-inclusive rate: every step uploads its 32 MB of scalars from host memory (bpg_msm, what a drop-in
     #      for multiscalar_mul(host scalars, resident points) does), `in_flight` host threads each on its own lane
     pcie = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         import threading
         per = max(2, args.steps // args.in_flight)
 
@@ -365,7 +366,7 @@ def main():
 
     # ---- strong scaling: ONE MSM of 2^20 (and of 2^22) points split N ways by point range; `value` above is the weak figure
     strong = {}
-    for logt in (20, 22):
+    for logt in (() if args.no_extras else (20, 22)):
         nl = (1 << logt) // world
         if world == 1 and logt == args.logn:
             strong["2^%d" % logt] = {"points_per_s": None, "note": "N = 1: the headline configuration itself"}
@@ -516,7 +517,7 @@ def main():
                          "hbm_algorithmic_GBps": BYTES_PER_POINT * n / (acc * 1e-6) / 1e9, "hbm_peak_GBps": 8000.0,
                          "traffic": ACC_TRAFFIC_BYTES_2_20 if args.logn == 20 else None},
         }
-        line["latency_ms"] = {"msm_resident_scalars": median(lat_res), "msm_host_scalars": median(lat_host) if lat_host else None,
+        line["latency_ms"] = {"msm_resident_scalars": median(lat_res) if lat_res else None, "msm_host_scalars": median(lat_host) if lat_host else None,
                               "note": "one 2^%d-point MSM with the GPU to itself, submit -> 32 result bytes on the host" % args.logn}
         if pcie is not None:
             line["pcie_inclusive"] = pcie

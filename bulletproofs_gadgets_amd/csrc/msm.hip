@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "bpg_internal.h"
 #include "hot25519.h"
 
@@ -1347,15 +1349,18 @@ static void msm_enqueue_sort(hipStream_t s, const msm_plan &pl, const msm_geom &
                        y.L.lv[g.nlevels > 1 ? 1 : 0], y.map0, y.map1, (uint32_t)g.NE, pl.ls0, pl.ls1);
 }
 
+// ev_start / ev_stop (may be null): recorded at the dispatch's own begin and end, the timestamps a kernel trace shows
+// (events recorded around the launch instead also time the barrier packets and the cache write-back between them)
 static void msm_enqueue_accumulate(hipStream_t s, const msm_plan &pl, const msm_geom &g, const msm_bufs &b, const msm_layout &y,
-                                   const seg_map &map, bool multi, uint32_t wstride) {
+                                   const seg_map &map, bool multi, uint32_t wstride, hipEvent_t ev_start = nullptr,
+                                   hipEvent_t ev_stop = nullptr) {
     const dim3 grid((unsigned)((g.cap_lv[0] + 255) / 256));
     if (multi)
-        hipLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), 0, s, b.entries, y.counts, y.ent_off, y.L.lv[0], y.map0,
-                           b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
+        hipExtLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
+                              y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
     else
-        hipLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), 0, s, b.entries, y.counts, y.ent_off, y.L.lv[0], y.map0,
-                           b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
+        hipExtLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
+                              y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
 }
 
 // merge passes and the bit-tree tail: leaves pl.outs points per bucket set in b.out
@@ -1443,9 +1448,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     // Accumulate passes of one lane's jobs run one after another: two of them at once only time-slice the
     // VALU, while the sort / merge / tail kernels of a later job do overlap usefully with an earlier job's pass.
     if (lane->acc_gate_job && lane->acc_gate_job != j) BPG_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
-    BPG_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    msm_enqueue_accumulate(s, pl, g, b, y, mm.map, nseg > 1, (uint32_t)fb.wstride);
-    BPG_CHECK_HIP(hipEventRecord(j->ev[2], s));
+    msm_enqueue_accumulate(s, pl, g, b, y, mm.map, nseg > 1, (uint32_t)fb.wstride, j->ev[1], j->ev[2]);
     lane->acc_gate_job = j;
     msm_enqueue_merge_tail(s, pl, g, b, y, T);
     BPG_CHECK_HIP(hipGetLastError());

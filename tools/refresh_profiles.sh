@@ -8,7 +8,7 @@ cd $R
 timeout -k 10 600 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 echo bench done >> $O/progress.log
 cd /tmp && export TMPDIR=/tmp
-MSM="--no-proofs --no-big-proof --no-batch --no-cpu-baseline"
+MSM="--no-proofs --no-big-proof --no-batch --no-cpu-baseline --no-extras"
 (cd $R && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/msm_stats -- python3 bench.py $MSM > $O/msm_stats.log 2>&1)
 echo stats done >> $O/progress.log
 (cd $R && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py $MSM --steps 6 --warmup 2 > $O/pmc_fetch.log 2>&1)
