@@ -101,6 +101,7 @@ def lib():
         "bpg_cs_constrain": (ci, [vp, u64p, cp, sz]),
         "bpg_cs_specify_randomized_constraints": (ci, [vp, RANDOMIZED_FN, vp]),
         "bpg_cs_challenge_scalar": (ci, [vp, cp, sz, cp]),
+        "bpg_flat_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
         "bpg_cs_export_terms": (ci, [vp, u64p, vp, ctypes.POINTER(ctypes.c_uint32), sz, psz]),
         "bpg_gadget_binary_constrain": (ci, [vp, ctypes.c_uint64]),
         "bpg_gadget_nonzero": (ci, [vp, u64p, cp, sz, cp]),
@@ -290,6 +291,12 @@ class Context:
         c, w, nb, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(lib().bpg_msm_plan(self._h, n, n_targets, ctypes.byref(c), ctypes.byref(w), ctypes.byref(nb), ctypes.byref(p)))
         return {"window_bits": c.value, "windows": w.value, "buckets": nb.value, "threads_per_bucket": p.value}
+
+    def flat_cache_stats(self):
+        """(hits, misses) of the circuit-structure cache since this context was created"""
+        h, m = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().bpg_flat_cache_stats(self._h, ctypes.byref(h), ctypes.byref(m)))
+        return h.value, m.value
 
     def msm_last_kernel_us(self):
         a, t = ctypes.c_float(), ctypes.c_float()

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -143,6 +144,11 @@ struct bpg_ctx {
     // this device's copy of the static workspace of bpg_msm_noalloc (msm.hip: msm_noalloc_init)
     void *noalloc_scratch = nullptr;
     size_t noalloc_scratch_bytes = 0;
+    // circuit-structure cache of the constraint flattening (r1cs.hip: flat_plan_cached): the counting-sorted term
+    // lists of recently seen circuits, resident in HBM; most recently used last.  Entries are immutable once listed.
+    std::mutex flat_mu;
+    std::vector<std::shared_ptr<void>> flat_cache;
+    std::atomic<uint64_t> flat_hits{0}, flat_misses{0};
 };
 
 namespace bpg {

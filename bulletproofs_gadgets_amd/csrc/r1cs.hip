@@ -563,6 +563,7 @@ static double now_ms() {
 struct FlatPlan {
     std::vector<uint32_t> slot_off, t_coeff, t_q, one_coeff, one_q;
     uint32_t nslots = 0, neg_from = 0;
+    size_t nterms = 0, nones = 0;          // t_coeff.size(), one_coeff.size() (kept when the vectors are dropped)
 };
 static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc, FlatPlan &fp) {
     fp.nslots = 3 * n + m;
@@ -600,42 +601,142 @@ static void build_flat_plan(const ConstraintStore &cs, uint32_t n, uint32_t m, b
         fp.t_coeff[pos] = cs.term_coeff[t];
         fp.t_q[pos] = cs.term_q[t];
     }
+    fp.nterms = fp.t_coeff.size();
+    fp.nones = fp.one_coeff.size();
+}
+
+// ---- circuit-structure cache ("cache the circuit structure across proofs of the same gadget").
+// The plan depends on the captured term list only -- which variable, which interned coefficient id, which
+// constraint -- not on the coefficient values or the witness, so every proof and every verification of one
+// circuit shares it: the reference's *_roundtrip_helper functions re-capture the same circuit per call
+// (ref: tests/edwards_point.rs:84-95).  A hit skips the counting sort and the upload of the term lists (12 bytes
+// per term); the key is compared in full, the hash only finds the candidate.
+struct FlatCached {
+    uint32_t n = 0, m = 0;
+    bool want_wc = false;
+    uint64_t hash = 0;
+    std::vector<uint32_t> term_var, term_coeff, term_q;     // the key
+    FlatPlan fp;                                            // sizes only (the vectors live in HBM)
+    uint32_t *d_off = nullptr, *d_tc = nullptr, *d_tq = nullptr, *d_oc = nullptr, *d_oq = nullptr;
+    void *d_block = nullptr;
+    ~FlatCached() {
+        if (d_block) (void)hipFree(d_block);
+    }
+};
+constexpr size_t FLAT_CACHE_ENTRIES = 8;
+
+// four independent multiply-xorshift lanes over 64-bit words (the term lists of a 2^20-multiplier circuit are tens of MB)
+static uint64_t hash_words(const std::vector<uint32_t> &v, uint64_t h) {
+    const uint64_t K = 0x9E3779B97F4A7C15ull;
+    uint64_t a[4] = {h, h ^ K, h + K, ~h};
+    const size_t n8 = v.size() / 8;
+    const uint32_t *p = v.data();
+    for (size_t i = 0; i < n8; i++, p += 8)
+        for (int l = 0; l < 4; l++) {
+            uint64_t w;
+            memcpy(&w, p + 2 * l, 8);
+            a[l] = (a[l] ^ w) * K;
+            a[l] ^= a[l] >> 29;
+        }
+    for (size_t i = n8 * 8; i < v.size(); i++) {
+        a[0] = (a[0] ^ v[i]) * K;
+        a[0] ^= a[0] >> 29;
+    }
+    uint64_t r = v.size();
+    for (int l = 0; l < 4; l++) {
+        r = (r ^ a[l]) * K;
+        r ^= r >> 32;
+    }
+    return r;
+}
+
+static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc,
+                            std::shared_ptr<FlatCached> &out) {
+    uint64_t h = 0x243F6A8885A308D3ull ^ ((uint64_t)n << 32) ^ m ^ (want_wc ? 1ull << 63 : 0);
+    h = hash_words(cs.term_var, h);
+    h = hash_words(cs.term_coeff, h);
+    h = hash_words(cs.term_q, h);
+    std::vector<std::shared_ptr<void>> candidates;
+    {
+        std::lock_guard<std::mutex> lk(ctx->flat_mu);
+        candidates = ctx->flat_cache;
+    }
+    for (auto &c : candidates) {
+        auto e = std::static_pointer_cast<FlatCached>(c);
+        if (e->hash == h && e->n == n && e->m == m && e->want_wc == want_wc && e->term_var == cs.term_var &&
+            e->term_coeff == cs.term_coeff && e->term_q == cs.term_q) {
+            std::lock_guard<std::mutex> lk(ctx->flat_mu);                  // most recently used last
+            auto it = std::find(ctx->flat_cache.begin(), ctx->flat_cache.end(), c);
+            if (it != ctx->flat_cache.end()) std::rotate(it, it + 1, ctx->flat_cache.end());
+            ctx->flat_hits++;
+            out = e;
+            return BPG_OK;
+        }
+    }
+    auto e = std::make_shared<FlatCached>();
+    e->n = n;
+    e->m = m;
+    e->want_wc = want_wc;
+    e->hash = h;
+    e->term_var = cs.term_var;
+    e->term_coeff = cs.term_coeff;
+    e->term_q = cs.term_q;
+    build_flat_plan(cs, n, m, want_wc, e->fp);
+    FlatPlan &fp = e->fp;
+    const size_t w_off = fp.nslots + 1, w_t = fp.nterms + 1, w_o = fp.nones + 1;
+    const size_t words = (w_off + 63) / 64 * 64 + 2 * ((w_t + 63) / 64 * 64) + 2 * ((w_o + 63) / 64 * 64);
+    BPG_CHECK_HIP(device_malloc(&e->d_block, words * 4));
+    uint32_t *p = (uint32_t *)e->d_block;
+    e->d_off = p;  p += (w_off + 63) / 64 * 64;
+    e->d_tc = p;   p += (w_t + 63) / 64 * 64;
+    e->d_tq = p;   p += (w_t + 63) / 64 * 64;
+    e->d_oc = p;   p += (w_o + 63) / 64 * 64;
+    e->d_oq = p;
+    hipStream_t s = lane->stream;
+    BPG_CHECK_HIP(hipMemcpyAsync(e->d_off, fp.slot_off.data(), w_off * 4, hipMemcpyHostToDevice, s));
+    if (fp.nterms) {
+        BPG_CHECK_HIP(hipMemcpyAsync(e->d_tc, fp.t_coeff.data(), fp.nterms * 4, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(e->d_tq, fp.t_q.data(), fp.nterms * 4, hipMemcpyHostToDevice, s));
+    }
+    if (fp.nones) {
+        BPG_CHECK_HIP(hipMemcpyAsync(e->d_oc, fp.one_coeff.data(), fp.nones * 4, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(hipMemcpyAsync(e->d_oq, fp.one_q.data(), fp.nones * 4, hipMemcpyHostToDevice, s));
+    }
+    BPG_CHECK_HIP(hipStreamSynchronize(s));                 // complete before any other thread's stream can read it
+    for (auto *v : {&fp.slot_off, &fp.t_coeff, &fp.t_q, &fp.one_coeff, &fp.one_q}) std::vector<uint32_t>().swap(*v);
+    {
+        std::lock_guard<std::mutex> lk(ctx->flat_mu);
+        if (ctx->flat_cache.size() >= FLAT_CACHE_ENTRIES) ctx->flat_cache.erase(ctx->flat_cache.begin());   // freed with its last user
+        ctx->flat_cache.push_back(e);
+        ctx->flat_misses++;
+    }
+    out = e;
+    return BPG_OK;
 }
 
 // runs k_zpow + k_flatten (+ k_dot_zpow for the constant terms); W (device) receives
 // nslots scalars; *d_one / *n_one receive the per-block partial sums of sum z^(q+1) c over
 // the constant terms (the caller adds them up and negates to get wc).
-static int gpu_flatten(bpg_lane *lane, Arena &ar, const ConstraintStore &cs, const FlatPlan &fp, const sc &z, sc *d_W,
+static int gpu_flatten(bpg_lane *lane, Arena &ar, const ConstraintStore &cs, const FlatCached &fc, const sc &z, sc *d_W,
                        sc **d_one = nullptr, size_t *n_one = nullptr) {
     hipStream_t s = lane->stream;
+    const FlatPlan &fp = fc.fp;
     const uint32_t Q = cs.num_constraints;
     sc ztbl[32];
     pow2_table(ztbl, z);
     sc *d_ztbl = ar.take<sc>(32), *d_zpow = ar.take<sc>(Q ? Q : 1), *d_coeffs = ar.take<sc>(cs.coeffs.size() ? cs.coeffs.size() : 1);
-    uint32_t *d_off = ar.take<uint32_t>(fp.nslots + 1), *d_tc = ar.take<uint32_t>(fp.t_coeff.size() + 1),
-             *d_tq = ar.take<uint32_t>(fp.t_q.size() + 1);
     BPG_CHECK_HIP(hipMemcpyAsync(d_ztbl, ztbl, sizeof ztbl, hipMemcpyHostToDevice, s));
     if (!cs.coeffs.empty())
         BPG_CHECK_HIP(hipMemcpyAsync(d_coeffs, cs.coeffs.data(), cs.coeffs.size() * sizeof(sc), hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_off, fp.slot_off.data(), (fp.nslots + 1) * 4, hipMemcpyHostToDevice, s));
-    if (!fp.t_coeff.empty()) {
-        BPG_CHECK_HIP(hipMemcpyAsync(d_tc, fp.t_coeff.data(), fp.t_coeff.size() * 4, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(d_tq, fp.t_q.data(), fp.t_q.size() * 4, hipMemcpyHostToDevice, s));
-    }
     if (Q) hipLaunchKernelGGL(k_zpow, dim3(grid256(Q)), dim3(256), 0, s, d_ztbl, d_zpow, Q);
     if (fp.nslots)
-        hipLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, d_off, d_tc, d_tq, d_coeffs, d_zpow, d_W,
+        hipLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, fc.d_off, fc.d_tc, fc.d_tq, d_coeffs, d_zpow, d_W,
                            fp.nslots, fp.neg_from);
     if (d_one) {
-        const size_t no = fp.one_coeff.size(), nb = grid256(no ? no : 1);
+        const size_t no = fp.nones, nb = grid256(no ? no : 1);
         *n_one = no ? nb : 0;
         *d_one = ar.take<sc>(nb);
-        if (no) {
-            uint32_t *d_oc = ar.take<uint32_t>(no), *d_oq = ar.take<uint32_t>(no);
-            BPG_CHECK_HIP(hipMemcpyAsync(d_oc, fp.one_coeff.data(), no * 4, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(d_oq, fp.one_q.data(), no * 4, hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_dot_zpow, dim3((unsigned)nb), dim3(256), 0, s, d_oc, d_oq, d_coeffs, d_zpow, (uint32_t)no, *d_one);
-        }
+        if (no) hipLaunchKernelGGL(k_dot_zpow, dim3((unsigned)nb), dim3(256), 0, s, fc.d_oc, fc.d_oq, d_coeffs, d_zpow, (uint32_t)no, *d_one);
     }
     BPG_CHECK_HIP(hipGetLastError());
     return BPG_OK;
@@ -643,8 +744,7 @@ static int gpu_flatten(bpg_lane *lane, Arena &ar, const ConstraintStore &cs, con
 
 static size_t flatten_bytes(const ConstraintStore &cs, const FlatPlan &fp) {
     return pad256(32 * 32) + pad256((cs.num_constraints + 1) * 32) + pad256((cs.coeffs.size() + 1) * 32) +
-           pad256((fp.nslots + 1) * 4) + 2 * pad256((fp.t_coeff.size() + 1) * 4) + 2 * pad256((fp.one_coeff.size() + 1) * 4) +
-           pad256((fp.one_coeff.size() / 256 + 2) * 32);
+           pad256((fp.nones / 256 + 2) * 32);
 }
 
 // =================================================================== generators
@@ -1078,7 +1178,7 @@ int Prover::prove_finish(R1CSProof &P) {
 // per round and proof.  g = 1 is the single proof.
 int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     struct PF {
-        FlatPlan fp;
+        std::shared_ptr<FlatCached> fc;
         sc *d_rows, *d_aL, *d_aR, *d_aO, *d_sL, *d_sR;
         sc *d_W, *d_ytbl, *d_yinvtbl, *d_l1, *d_r0, *d_r1, *d_r3, *d_part;
         sc *d_a, *d_b, *d_sG, *d_sH, *d_rowLR, *d_cpart;
@@ -1121,8 +1221,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256(g * 2 * fm * 128) + (1 << 16);
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
-        build_flat_plan(p.cs_, (uint32_t)n, (uint32_t)p.v_.size(), false, pf[j].fp);
-        need += 5 * pad256((n + 1) * 32) + pad256((pf[j].fp.nslots + 1) * 32) + flatten_bytes(p.cs_, pf[j].fp) +
+        int rcf = flat_plan_cached(ctx, lane, p.cs_, (uint32_t)n, (uint32_t)p.v_.size(), false, pf[j].fc);
+        if (rcf) return rcf;
+        need += 5 * pad256((n + 1) * 32) + pad256((pf[j].fc->fp.nslots + 1) * 32) + flatten_bytes(p.cs_, pf[j].fc->fp) +
                 4 * pad256((n + 1) * 32) + pad256(nblk_n * 6 * 32) + 2 * pad256(32 * 32) + 4 * pad256(np * 32) +
                 pad256(nblk_np * 2 * 32) + (1 << 12);
     }
@@ -1202,8 +1303,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         }
         f.y = p.tr_.challenge_scalar("y");
         f.z = p.tr_.challenge_scalar("z");
-        f.d_W = ar.take<sc>(f.fp.nslots + 1);
-        if ((rc = gpu_flatten(lane, ar, p.cs_, f.fp, f.z.v, f.d_W))) return rc;
+        f.d_W = ar.take<sc>(f.fc->fp.nslots + 1);
+        if ((rc = gpu_flatten(lane, ar, p.cs_, *f.fc, f.z.v, f.d_W))) return rc;
         const Scalar y_inv = f.y.invert();
         pow2_table(f.ytbl, f.y.v);
         pow2_table(f.yinvtbl, y_inv.v);
@@ -1501,8 +1602,9 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     dyn.insert(dyn.end(), P.L_vec.begin(), P.L_vec.end());
     dyn.insert(dyn.end(), P.R_vec.begin(), P.R_vec.end());
 
-    FlatPlan fp;
-    build_flat_plan(cs_, (uint32_t)n, (uint32_t)m, true, fp);
+    std::shared_ptr<FlatCached> fc;
+    if ((rc = flat_plan_cached(ctx, lane, cs_, (uint32_t)n, (uint32_t)m, true, fc))) return rc;
+    const FlatPlan &fp = fc->fp;
     const size_t NS = 2 * np + 2 + ndyn, nblk = grid256(np);
     size_t need = pad256((fp.nslots + 1) * 32) + flatten_bytes(cs_, fp) + pad256(32 * 32) + 2 * pad256((lg + 1) * 32) +
                   pad256(NS * 32) + pad256(nblk * 32) + (1 << 16);
@@ -1511,7 +1613,7 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     sc *d_W = ar.take<sc>(fp.nslots + 1);
     sc *d_one = nullptr;
     size_t n_one = 0;
-    if ((rc = gpu_flatten(lane, ar, cs_, fp, z.v, d_W, &d_one, &n_one))) return rc;
+    if ((rc = gpu_flatten(lane, ar, cs_, *fc, z.v, d_W, &d_one, &n_one))) return rc;
     sc yinvtbl[32];
     pow2_table(yinvtbl, y.invert().v);
     sc *d_yinvtbl = ar.take<sc>(32), *d_uk = ar.take<sc>(lg + 1), *d_ukinv = ar.take<sc>(lg + 1);

@@ -317,6 +317,13 @@ int bpg_cs_challenge_scalar(bpg_cs *rcs, const uint8_t *label, size_t label_len,
     });
 }
 
+int bpg_flat_cache_stats(bpg_ctx *ctx, uint64_t *hits, uint64_t *misses) {
+    if (!ctx || !hits || !misses) return BPG_EINVAL;
+    *hits = ctx->flat_hits.load();
+    *misses = ctx->flat_misses.load();
+    return BPG_OK;
+}
+
 int bpg_cs_export_terms(const bpg_cs *cs, uint64_t *vars, uint8_t *coeffs32, uint32_t *constraint, size_t cap, size_t *n_terms) {
     if (!cs || !n_terms) return BPG_EINVAL;
     const ConstraintStore &st = cs->cs->store();

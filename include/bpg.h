@@ -244,6 +244,12 @@ typedef int (*bpg_randomized_fn)(void *user, bpg_cs *rcs);
 int bpg_cs_specify_randomized_constraints(bpg_cs *cs, bpg_randomized_fn callback, void *user);
 int bpg_cs_challenge_scalar(bpg_cs *rcs, const uint8_t *label, size_t label_len, uint8_t out32[32]);
 
+/* The library keeps the flattened structure of the last few circuits it has proved or verified resident on the GPU
+ * (which variable, coefficient and constraint each term belongs to, sorted by variable), so repeated proofs of one
+ * gadget -- what every *_roundtrip_helper of the reference does, ref: tests/edwards_point.rs:84-95 -- skip that
+ * work after the first.  Counters since bpg_init: lookups that found the circuit / that had to build it. */
+int bpg_flat_cache_stats(bpg_ctx *ctx, uint64_t *hits, uint64_t *misses);
+
 /* The constraint system as captured so far, one record per linear-combination term in capture order:
  * vars[t] (packed as above), coeffs32[t] (32 bytes), constraint[t] (index of the constrain() call, counting the two
  * implicit ones of each multiply()).  *n_terms is always set; BPG_EINVAL if cap is too small.  No counterpart in

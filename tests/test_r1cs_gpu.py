@@ -469,3 +469,25 @@ def test_allocation_failure_releases_jobs_and_workspaces(gpu_ctx, rnd):
             assert ok2 and again.to_bytes() == clean.to_bytes()
         finally:
             ctx2.close()
+
+
+def test_circuit_structure_cache(gpu_ctx, gbe, obe, rnd):
+    """a second proof of the same circuit reuses the resident term lists, whatever its public constants
+    and witness are; the bytes stay those of the oracle.  A different circuit is a different entry."""
+    h0, m0 = gpu_ctx.flat_cache_stats()
+    p1, p2, q1, q2 = (sonny.random_point(rnd) for _ in range(4))
+    assert _both(rc.addition_roundtrip, gbe, obe, p1, p2, p1 + p2, seed=b"c1")
+    h1, m1 = gpu_ctx.flat_cache_stats()
+    assert _both(rc.addition_roundtrip, gbe, obe, q1, q2, q1 + q2, seed=b"c2")     # other points, same circuit
+    h2, m2 = gpu_ctx.flat_cache_stats()
+    assert m2 == m1 and h2 >= h1 + 2                     # prover and verifier both found it
+    assert m1 - m0 <= 2                                  # at most: the prover's plan and the verifier's (with constants)
+    assert _both(rc.double_roundtrip, gbe, obe, p1, p1.double(), seed=b"c3")
+    h3, m3 = gpu_ctx.flat_cache_stats()
+    assert m3 >= m2 + 1 or h3 > h2                       # another circuit: its own entry (or already resident from an earlier test)
+    # more circuits than the cache holds: the oldest entries go, results stay right
+    for k in range(2, 13):
+        bits = [rnd.randrange(2) for _ in range(k)]
+        base = sonny.random_point(rnd)
+        assert _both(rc.scalar_mul_roundtrip, gbe, obe, base, bits, base * sum(b << i for i, b in enumerate(bits)), seed=b"c%d" % k)
+    assert _both(rc.addition_roundtrip, gbe, obe, p1, p2, p1 + p2, seed=b"c1")
