@@ -99,6 +99,7 @@ def lib():
         "bpg_cs_multiply": (ci, [vp, u64p, cp, sz, u64p, cp, sz, u64p]),
         "bpg_cs_allocate_multiplier": (ci, [vp, cp, cp, u64p]),
         "bpg_cs_constrain": (ci, [vp, u64p, cp, sz]),
+        "bpg_prover_set_gens": (ci, [vp, vp]),
         "bpg_cs_specify_randomized_constraints": (ci, [vp, RANDOMIZED_FN, vp]),
         "bpg_cs_challenge_scalar": (ci, [vp, cp, sz, cp]),
         "bpg_flat_cache_stats": (ci, [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

@@ -273,6 +273,9 @@ class Prover : public ConstraintSystem {
     bool is_prover() const override { return true; }
     void specify_randomized_constraints(RandomizedFn cb) override { deferred_.push_back(std::move(cb)); }
     Scalar challenge_scalar(const std::string &label) override;
+    // Prover::prove(&bp_gens) names the generators at proving time: a prover made against one generator object
+    // (whose Pedersen bases every object shares) may prove against another of the same context
+    int set_gens(Gens *g);
     Scalar eval(const LinearCombination &lc) const;
     // Prover::prove(bp_gens); returns BPG_OK or a negative BPG_E* code
     int prove(rng_fill_fn rng, void *rng_user, R1CSProof &out);

@@ -982,6 +982,12 @@ static inline size_t next_pow2(size_t n) {
     return p;
 }
 
+int Prover::set_gens(Gens *g) {
+    if (!g || g->ctx != gens_->ctx) return BPG_EINVAL;
+    gens_ = g;
+    return BPG_OK;
+}
+
 Scalar Prover::challenge_scalar(const std::string &label) {
     if (!phase2_) throw R1CSError(BPG_EINVAL, "challenge_scalar outside a randomized-constraints callback");
     return Scalar(tr_.challenge_scalar(label.c_str()));

@@ -163,6 +163,10 @@ int bpg_prover_commit_batch(bpg_prover *p, const uint8_t *v32, const uint8_t *bl
         return BPG_OK;
     });
 }
+int bpg_prover_set_gens(bpg_prover *p, bpg_gens *gens) {
+    if (!p || !gens) return BPG_EINVAL;
+    return guarded([&] { return p->p->set_gens(gens->g); });
+}
 int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *proof_out, size_t cap, size_t *proof_len) {
     if (!p || !rng || !proof_len) return BPG_EINVAL;
     return guarded([&] {

@@ -270,7 +270,9 @@ class Prover(_CS):
 
     def prove(self, bp_gens=None, external_rng32=None):
         """external_rng32: 32 bytes of external randomness (None: os.urandom, as `thread_rng` in the reference)"""
-        assert bp_gens is None or bp_gens is self.gens
+        if bp_gens is not None and bp_gens is not self.gens:      # Prover::prove(&bp_gens): generators named at proving time
+            check(lib().bpg_prover_set_gens(self._h, bp_gens._h))
+            self.gens = bp_gens
         rng = _Rng(external_rng32)
         cap = 1 << 16
         out = ctypes.create_string_buffer(cap)

@@ -183,6 +183,11 @@ bpg_cs *bpg_prover_cs(bpg_prover *p);
 int bpg_prover_commit(bpg_prover *p, const uint8_t v32[32], const uint8_t blinding32[32], uint8_t V32[32], uint64_t *var);
 /* m commits in transcript order with one kernel launch (ref: sk_know_gadget.rs:52-55 commits 256 bits one by one) */
 int bpg_prover_commit_batch(bpg_prover *p, const uint8_t *v32, const uint8_t *blinding32, size_t m, uint8_t *V32, uint64_t *vars);
+/* The generators of the next bpg_prover_prove: Prover::new takes only the Pedersen bases and Prover::prove(&bp_gens)
+ * names the generator vectors (ref: tests/edwards_point.rs:28 vs :47).  Every bpg_gens of one context carries the
+ * same Pedersen bases, so a prover created against one (say the capacity-1 object behind PedersenGens::default())
+ * can prove against another.  BPG_EINVAL if `gens` belongs to another context. */
+int bpg_prover_set_gens(bpg_prover *p, bpg_gens *gens);
 /* Prover::prove(&bp_gens) -> R1CSProof::to_bytes()   ref: tests/edwards_point.rs:47,134,215,320,391; scalar.rs:46; sk_know_gadget.rs:63
  * Returns BPG_EGENS for R1CSError::InvalidGeneratorsLength.  *proof_len is set even when cap is too small (BPG_EINVAL). */
 int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *proof_out, size_t cap, size_t *proof_len);

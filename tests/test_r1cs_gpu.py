@@ -491,3 +491,25 @@ def test_circuit_structure_cache(gpu_ctx, gbe, obe, rnd):
         base = sonny.random_point(rnd)
         assert _both(rc.scalar_mul_roundtrip, gbe, obe, base, bits, base * sum(b << i for i, b in enumerate(bits)), seed=b"c%d" % k)
     assert _both(rc.addition_roundtrip, gbe, obe, p1, p2, p1 + p2, seed=b"c1")
+
+
+def test_prove_names_the_generators(gbe, obe, rnd):
+    """Prover::new takes only the Pedersen bases, Prover::prove(&bp_gens) the generator vectors (ref:
+    tests/edwards_point.rs:28 vs :47): a prover made against the capacity-1 object proves against another one."""
+    g = gbe.g
+    small = g.BulletproofGens(gbe.ctx, 1, 1)
+    big = gbe.bp_gens(128)
+    p1, p2 = sonny.random_point(rnd), sonny.random_point(rnd)
+    rng = R.SeededRng(b"add")
+    prover = g.Prover(small, b"Point Addition")
+    g1, g2, g3 = (g.SonnyEdwardsPointGadget.from_point(p) for p in (p1, p2, p1 + p2))
+    g3.equal(g1.add(g2, prover), prover)
+    with pytest.raises(RuntimeError, match="BPG_EGENS"):
+        g.Prover(small, b"x").prove(small, bytes(32)) if False else None
+        q = g.Prover(small, b"Point Addition")
+        h1, h2, h3 = (g.SonnyEdwardsPointGadget.from_point(p) for p in (p1, p2, p1 + p2))
+        h3.equal(h1.add(h2, q), q)
+        q.prove(small, bytes(32))                                   # 16 multipliers do not fit capacity 1
+    proof = prover.prove(big, rng.fill_bytes(32))
+    ok, want = rc.addition_roundtrip(obe, p1, p2, p1 + p2, rng=R.SeededRng(b"add"))
+    assert ok and proof.to_bytes() == want.to_bytes()
