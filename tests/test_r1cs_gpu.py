@@ -505,7 +505,6 @@ def test_prove_names_the_generators(gbe, obe, rnd):
     g1, g2, g3 = (g.SonnyEdwardsPointGadget.from_point(p) for p in (p1, p2, p1 + p2))
     g3.equal(g1.add(g2, prover), prover)
     with pytest.raises(RuntimeError, match="BPG_EGENS"):
-        g.Prover(small, b"x").prove(small, bytes(32)) if False else None
         q = g.Prover(small, b"Point Addition")
         h1, h2, h3 = (g.SonnyEdwardsPointGadget.from_point(p) for p in (p1, p2, p1 + p2))
         h3.equal(h1.add(h2, q), q)
