@@ -241,7 +241,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
     ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "24")))
-    ap.add_argument("--proofs-per-thread", type=int, default=8)
+    ap.add_argument("--proofs-per-thread", type=int, default=32, help="per host thread, in calls of --proofs-per-call (long enough for the threads to fall out of step: host and GPU phases of different threads then overlap)")
     ap.add_argument("--proofs-per-call", type=int, default=8, help="statements per bpg_prover_prove_many call (1: plain prove calls)")
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")

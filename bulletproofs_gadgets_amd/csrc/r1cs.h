@@ -311,6 +311,12 @@ class Prover : public ConstraintSystem {
     std::unique_ptr<TranscriptRng> rng_;
     sc i_bl_, o_bl_, s_bl_;
     std::vector<sc> s_L_, s_R_;
+    // one-phase proofs of RAW_DRAW_MIN multipliers or more keep the blinding draws as the RNG delivers them -- 64
+    // bytes each, s_L then s_R -- and a kernel reduces them mod l (k_reduce512): on the host that reduction is about
+    // half of the drawing time once eight Keccak states advance per permutation
+    std::vector<uint8_t> s_raw_;
+    static constexpr size_t RAW_DRAW_MIN = 256;
+    bool raw_draws() const { return deferred_.empty() && a_L_.size() >= RAW_DRAW_MIN; }
     double t_start_ = 0;
 };
 

@@ -328,6 +328,19 @@ __global__ void __launch_bounds__(256) k_axpy(uint32_t n, sc rho, const sc *__re
     st_sc(acc + i, a);
 }
 
+// Scalar::random's second half: 64 bytes of RNG output -> a scalar mod l (dalek: Scalar::from_bytes_mod_order_wide).
+// raw[i] = 16 little-endian words; out[i] = raw[i] mod l.
+__global__ void __launch_bounds__(256) k_reduce512(const uint4 *__restrict__ raw, sc *__restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint4 a = raw[4 * (size_t)i], b = raw[4 * (size_t)i + 1], c = raw[4 * (size_t)i + 2], d = raw[4 * (size_t)i + 3];
+    sc lo, hi, r;
+    lo.v[0] = a.x; lo.v[1] = a.y; lo.v[2] = a.z; lo.v[3] = a.w; lo.v[4] = b.x; lo.v[5] = b.y; lo.v[6] = b.z; lo.v[7] = b.w;
+    hi.v[0] = c.x; hi.v[1] = c.y; hi.v[2] = c.z; hi.v[3] = c.w; hi.v[4] = d.x; hi.v[5] = d.y; hi.v[6] = d.z; hi.v[7] = d.w;
+    sc_reduce512(r, lo, hi);
+    st_sc(out + i, r);
+}
+
 // K3: fixed-base Pedersen commitments v B + r B~ with radix-16 comb tables, compressed on the device.
 // comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels).  16 lanes per commitment: lane l
 // adds the windows w = l mod 16 of both scalars (8 mixed additions), four butterfly steps sum the
@@ -1110,10 +1123,15 @@ void Prover::draw_blindings() {
     i_bl_ = rng_->scalar();
     o_bl_ = rng_->scalar();
     s_bl_ = rng_->scalar();
-    s_L_.resize(n);
-    s_R_.resize(n);
-    for (size_t i = 0; i < n; i++) s_L_[i] = rng_->scalar();
-    for (size_t i = 0; i < n; i++) s_R_[i] = rng_->scalar();
+    if (raw_draws()) {
+        s_raw_.resize(128 * n);
+        for (size_t i = 0; i < 2 * n; i++) rng_->fill_bytes(&s_raw_[64 * i], 64);        // s_L[0..n) then s_R[0..n)
+    } else {
+        s_L_.resize(n);
+        s_R_.resize(n);
+        for (size_t i = 0; i < n; i++) s_L_[i] = rng_->scalar();
+        for (size_t i = 0; i < n; i++) s_R_[i] = rng_->scalar();
+    }
     timing.rng_ms = now_ms() - t0;
 }
 
@@ -1127,6 +1145,7 @@ int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rn
         const size_t n = ps[j0]->a_L_.size();
         bool same = g > 1;
         for (size_t l = 1; l < g; l++) same = same && ps[j0 + l]->a_L_.size() == n;
+        for (size_t l = 0; l < g; l++) same = same && ps[j0 + l]->deferred_.empty();
         TranscriptRng *r[8];
         for (size_t l = 0; l < 8; l++) r[l] = ps[j0 + (l < g ? l : 0)]->rng_.get();     // spare lanes repeat lane 0
         TranscriptRngLanes8 lanes;
@@ -1142,17 +1161,26 @@ int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rn
         for (size_t l = 0; l < g; l++) ps[j0 + l]->o_bl_ = d[l];
         lanes.scalars(d);
         for (size_t l = 0; l < g; l++) ps[j0 + l]->s_bl_ = d[l];
-        for (size_t l = 0; l < g; l++) {
-            ps[j0 + l]->s_L_.resize(n);
-            ps[j0 + l]->s_R_.resize(n);
-        }
-        for (size_t i = 0; i < n; i++) {
-            lanes.scalars(d);
-            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_L_[i] = d[l];
-        }
-        for (size_t i = 0; i < n; i++) {
-            lanes.scalars(d);
-            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_R_[i] = d[l];
+        if (ps[j0]->raw_draws()) {
+            uint8_t buf[8][64];
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_raw_.resize(128 * n);
+            for (size_t i = 0; i < 2 * n; i++) {
+                lanes.fill64(buf);
+                for (size_t l = 0; l < g; l++) memcpy(&ps[j0 + l]->s_raw_[64 * i], buf[l], 64);
+            }
+        } else {
+            for (size_t l = 0; l < g; l++) {
+                ps[j0 + l]->s_L_.resize(n);
+                ps[j0 + l]->s_R_.resize(n);
+            }
+            for (size_t i = 0; i < n; i++) {
+                lanes.scalars(d);
+                for (size_t l = 0; l < g; l++) ps[j0 + l]->s_L_[i] = d[l];
+            }
+            for (size_t i = 0; i < n; i++) {
+                lanes.scalars(d);
+                for (size_t l = 0; l < g; l++) ps[j0 + l]->s_R_[i] = d[l];
+            }
         }
         lanes.store(r, (int)g);
         const double per = (now_ms() - t0) / (double)g;
@@ -1224,7 +1252,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     const size_t fm = k0 ? np >> k0 : 0;                  // folded generators per side
     // MSM scalar rows: 2g rows of NR before the fold, of g * 2 fm + 1 after it
     const size_t row_words = std::max(g * 2 * NR, 2 * g * (g * 2 * fm + 1));
-    size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256(g * 2 * fm * 128) + (1 << 16);
+    size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256(g * 2 * fm * 128) + (1 << 16) +
+                  g * pad256(128 * n + 64);
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         int rcf = flat_plan_cached(ctx, lane, p.cs_, (uint32_t)n, (uint32_t)p.v_.size(), false, pf[j].fc);
@@ -1242,14 +1271,17 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     aniels_rec *d_tab_all = (aniels_rec *)ar.take<uint8_t>(g * 2 * fm * 128 + 128);   // proof j: [G' (fm) | H' (fm)]
     BPG_CHECK_HIP(hipMemsetAsync(d_rows_all, 0, g * 3 * N1 * 32, s));
     std::vector<std::vector<sc>> keep_sL(g), keep_sR(g);  // pageable sources of async copies: alive until the sync
+    std::vector<std::vector<uint8_t>> keep_raw(g);
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         PF &f = pf[j];
         // the blinding vectors are only needed up to the upload; the prover keeps nothing of them afterwards
         keep_sL[j] = std::move(p.s_L_);
         keep_sR[j] = std::move(p.s_R_);
+        keep_raw[j] = std::move(p.s_raw_);
         p.s_L_.clear();
         p.s_R_.clear();
+        p.s_raw_.clear();
         f.d_rows = d_rows_all + j * 3 * N1;
         f.d_aL = f.d_rows + 1;                              // row 0 = [i_bl | a_L | a_R]
         f.d_aR = f.d_rows + 1 + n;
@@ -1263,13 +1295,22 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, p.a_L_.data(), n * 32, hipMemcpyHostToDevice, s));
             BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, p.a_R_.data(), n * 32, hipMemcpyHostToDevice, s));
             BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, p.a_O_.data(), n * 32, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_sL, keep_sL[j].data(), n * 32, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_sR, keep_sR[j].data(), n * 32, hipMemcpyHostToDevice, s));
+            if (!keep_raw[j].empty()) {              // raw draws: reduced mod l on the device, straight into row 2
+                if (keep_raw[j].size() != 128 * n) return BPG_EINVAL;
+                uint4 *d_raw = (uint4 *)ar.take<uint8_t>(128 * n);
+                BPG_CHECK_HIP(hipMemcpyAsync(d_raw, keep_raw[j].data(), 128 * n, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_reduce512, dim3(grid256(2 * n)), dim3(256), 0, s, d_raw, f.d_sL, (uint32_t)(2 * n));
+            } else {
+                if (keep_sL[j].size() != n || keep_sR[j].size() != n) return BPG_EINVAL;
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sL, keep_sL[j].data(), n * 32, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sR, keep_sR[j].data(), n * 32, hipMemcpyHostToDevice, s));
+            }
         }
     }
     BPG_CHECK_HIP(hipStreamSynchronize(s));
     keep_sL.clear();
     keep_sR.clear();
+    keep_raw.clear();
 
     // ---- A_I1, A_O1, S1 of every proof: one 3g-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
