@@ -197,7 +197,11 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
             raw = (uint32_t)(two >> off) & mask;
         }
         raw += carry;
-        carry = raw > half ? 1u : 0u;
+        // raw == half stays (no carry), which is what keeps the top window from carrying out when c divides 252.
+        // At c = 16 a stored digit must also fit int16: the tie then carries when the digit is stored as it is
+        // (d = -2^15 instead of +2^15; stored negated, +2^15 becomes -2^15).  The top window of c = 16 holds 12 bits:
+        // no tie there.
+        carry = (raw > half || (C == 16 && !flip && raw == half)) ? 1u : 0u;
         int d = (int)raw - (int)(carry << C);
         out[(size_t)w * n] = (int16_t)(flip ? -d : d);
     }
@@ -1066,13 +1070,16 @@ static int ilog2(size_t x) {
     return r;
 }
 
-// variable-base window size: the divisor of 252 that minimises windows * (n + 4 * buckets)
+// variable-base window size: the candidate that minimises windows * (n + 18 * buckets).  The weight of a bucket is
+// measured, not counted (a bucket costs ~2 full additions in the merge and tail kernels, which run far below the
+// accumulate kernel's rate): at n = 2^20, c = 16 takes 1.234 ms per MSM against 1.010 ms for c = 14 although its
+// accumulate pass is shorter; at 2^22 the two tie (4.16 ms); beyond that c = 16 wins.  (profiles/r02_window_sweep.txt)
 static int auto_window(size_t n) {
-    static const int cand[] = {4, 6, 7, 9, 12, 14};
+    static const int cand[] = {4, 6, 7, 9, 12, 14, 16};
     int best = 4;
     double best_cost = 1e300;
     for (int c : cand) {
-        double cost = (double)windows_for(c) * ((double)n + 4.0 * (double)(1u << (c - 1)));
+        double cost = (double)windows_for(c) * ((double)n + 18.0 * (double)(1u << (c - 1)));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -1097,7 +1104,7 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float d
     size_t n_eff = n;
     if (!fixed_c && density > 0.f && density < 1.f) n_eff = (size_t)((double)n * density) + 1;
     int c = auto_window(n_eff);
-    if (tune.c >= 2 && tune.c <= 14) c = tune.c;
+    if (tune.c >= 2 && tune.c <= 16) c = tune.c;
     if (fixed_c) c = fixed_c;
     pl.c = c;
     pl.W = windows_for(c);
@@ -1177,7 +1184,7 @@ static void dispatch_digits(int c, hipStream_t s, const uint32_t *sc, int16_t *d
     switch (c) {
 #define BPG_CASE(C) case C: launch_digits<C>(s, sc, dg, n, total, sm, zero, nzero); break;
         BPG_CASE(2) BPG_CASE(3) BPG_CASE(4) BPG_CASE(5) BPG_CASE(6) BPG_CASE(7) BPG_CASE(8) BPG_CASE(9)
-        BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14)
+        BPG_CASE(10) BPG_CASE(11) BPG_CASE(12) BPG_CASE(13) BPG_CASE(14) BPG_CASE(15) BPG_CASE(16)
 #undef BPG_CASE
     }
 }
@@ -1223,7 +1230,8 @@ void msm_job_destroy(bpg_msm_job *j) {
 struct msm_geom {
     size_t NE, M, nblk, lvl_words, map_words, NBT, NCH, part_total;
     size_t cap_lv[MAX_LEVELS], part_off[MAX_LEVELS];
-    int nlevels, logchunk, lognch, per0, LOWN;
+    int nlevels, logchunk, lognch, per0, LOWN, ngroups;
+    size_t chunk2_off;
     uint32_t CH;
     // bytes of each workspace buffer
     size_t b_digits, b_entries, b_counts, b_tmp, b_partials, b_chunk, b_out;
@@ -1272,7 +1280,10 @@ static int msm_geometry(const msm_plan &pl, size_t n, int T, msm_geom &g) {
     g.b_counts = (2 * g.NE + (size_t)(g.nlevels + 1) * g.lvl_words + g.map_words + 4 * g.NBT + g.NCH * (size_t)g.LOWN + 16) * sizeof(uint32_t);
     g.b_tmp = g.M * sizeof(uint2) + 64;                    // level-1 output: (entry, bucket in bin)
     g.b_partials = g.part_total * sizeof(ge_rec);
-    g.b_chunk = (size_t)T * pl.Wb * pl.nchunks * g.per0 * sizeof(ge_rec);
+    // tail: chunks of 256 buckets -> (more than 32 chunks per window: groups of 32 chunks ->) one set of c points per window
+    g.ngroups = pl.nchunks > 32 ? pl.nchunks / 32 : 0;
+    g.chunk2_off = (size_t)T * pl.Wb * pl.nchunks * g.per0;
+    g.b_chunk = (g.chunk2_off + (size_t)T * pl.Wb * g.ngroups * (g.per0 + 5)) * sizeof(ge_rec);
     g.b_out = (size_t)T * pl.Wb * pl.outs * sizeof(ge_rec);
     return BPG_OK;
 }
@@ -1380,7 +1391,14 @@ static void msm_enqueue_merge_tail(hipStream_t s, const msm_plan &pl, const msm_
     ge_rec *a_out = pl.nchunks == 1 ? b.out : b.chunk;
     hipLaunchKernelGGL(k_tail_a, dim3(pl.nchunks, pl.Wb, T), dim3(pl.chunk), (size_t)pl.chunk * 128, s, y.L, y.counts, a_out, pl.NB,
                        pl.chunk, g.logchunk, pl.Wb, pl.ls0, pl.ls1);
-    if (pl.nchunks > 1)
+    if (pl.nchunks > 32) {
+        // 2^15 buckets per window (c = 16) are 128 chunks: 32 at a time (288 tree slots per block), then the 4 groups
+        ge_rec *mid = b.chunk + g.chunk2_off;
+        const int Wg = pl.Wb * g.ngroups, per1 = g.per0 + 5;
+        hipLaunchKernelGGL(k_tail_b, dim3(Wg, T), dim3(320), (size_t)32 * g.per0 * 128, s, b.chunk, mid, 32, 5, g.per0, Wg);
+        hipLaunchKernelGGL(k_tail_b, dim3(pl.Wb, T), dim3(320), (size_t)g.ngroups * per1 * 128, s, mid, b.out, g.ngroups,
+                           ilog2(g.ngroups), per1, pl.Wb);
+    } else if (pl.nchunks > 1)
         hipLaunchKernelGGL(k_tail_b, dim3(pl.Wb, T), dim3(320), (size_t)pl.nchunks * g.per0 * 128, s, b.chunk, b.out, pl.nchunks,
                            g.lognch, g.per0, pl.Wb);
 }

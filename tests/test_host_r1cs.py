@@ -44,6 +44,11 @@ def test_gadget_shapes_match_survey_and_oracle(oracle):
         return v.num_vars, len(v.constraints)
     assert n_from_point == oracle_count(lambda cs: OG.SonnyRistrettoPointGadget.from_point(rp, cs))
 
+    # from_lcs: the Ristretto gadget over four linear combinations, no point assignment (ref: ristretto_point.rs:34-45)
+    coords = [p.X, p.Y, p.Z, p.T]
+    assert _count(lambda cs: g.SonnyRistrettoPointGadget.from_lcs(gp, 4, cs)) == \
+        oracle_count(lambda cs: OG.SonnyRistrettoPointGadget.from_lcs(coords, cs))
+
     def smul(cs, EG):
         bits = [cs.commit(bytes(32)) for _ in range(5)]
         EG.scalar_mul(EG.from_point(p), bits, cs)

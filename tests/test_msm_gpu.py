@@ -213,7 +213,8 @@ def test_msm_full_size_skewed(gpu_ctx):
 @pytest.mark.parametrize("env", [{"BPG_MSM_LS0": "1"}, {"BPG_MSM_LS0": "5"}, {"BPG_MSM_LS0": "23", "BPG_MSM_LS1": "3"},
                                  {"BPG_MSM_C": "9", "BPG_MSM_TILE": "512"}, {"BPG_MSM_C": "12", "BPG_MSM_LS0": "64"},
                                  {"BPG_MSM_C": "6", "BPG_MSM_LS1": "2"}, {"BPG_MSM_SORT_CHUNK": "256"},
-                                 {"BPG_MSM_C": "12", "BPG_MSM_SORT_CHUNK": "300"}])
+                                 {"BPG_MSM_C": "12", "BPG_MSM_SORT_CHUNK": "300"},
+                                 {"BPG_MSM_C": "15"}, {"BPG_MSM_C": "16"}, {"BPG_MSM_C": "16", "BPG_MSM_LS0": "3"}])
 def test_msm_planner_overrides(oracle, env):
     """every geometry the planner can be pushed into (segment size S0 not a power of two, narrow and wide
     merge passes, deep merge trees, small tiles, one and many buckets per bin, many level-2 chunks per bin) gives the oracle's bytes,
@@ -235,8 +236,11 @@ def test_msm_planner_overrides(oracle, env):
         u = synth.uniform_bytes(n, tag=b"ovr")
         pts = ctx.points_from_uniform(u)
         arr, _ = oracle.from_uniform(u)
+        # l - 1, (l - 1) / 2, (l + 1) / 2 and 2^15-aligned values: the digit that is exactly half a window at c = 16
+        edge = [L - 1, (L - 1) // 2, (L + 1) // 2, 1 << 15, (1 << 15) + (1 << 31), L - (1 << 15), (1 << 252) - 1, 0x8000800080008000]
+        edge_sc = _scalars_from_ints([edge[i % len(edge)] for i in range(n)])
         for sc in (synth.scalars(n, tag=b"ovr-s"), synth.small_scalars(n, 1, tag=b"ovr-b"), synth.small_scalars(n, 9, tag=b"ovr-9"),
-                   synth.scalars(1, tag=b"ovr-e") * n):
+                   synth.scalars(1, tag=b"ovr-e") * n, edge_sc):
             assert ctx.msm(pts, sc) == oracle.msm(sc, arr, n)
     finally:
         ctx.close()

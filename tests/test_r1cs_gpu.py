@@ -512,3 +512,23 @@ def test_prove_names_the_generators(gbe, obe, rnd):
     proof = prover.prove(big, rng.fill_bytes(32))
     ok, want = rc.addition_roundtrip(obe, p1, p2, p1 + p2, rng=R.SeededRng(b"add"))
     assert ok and proof.to_bytes() == want.to_bytes()
+
+
+def test_missing_assignment(gbe):
+    """R1CSError::MissingAssignment: a prover asked for a multiplier without its inputs (ConstraintSystem::
+    allocate_multiplier(None)); the reference reaches it through from_lcs on a prover, whose nonzero gadget has no
+    assignment to give (ref: ristretto_point.rs:34-45 -> :50-90 -> scalar.rs:9-26)."""
+    from bulletproofs_gadgets_amd import BpgError, _native
+    gbe.bp_gens(64)
+    p = gbe.Prover(b"missing")
+    with pytest.raises(BpgError) as e:
+        p.allocate_multiplier(None)
+    assert e.value.code == _native.EMISSING
+    gp = gbe.g.SonnyEdwardsPointGadget.from_point(sonny.BASEPOINT)
+    with pytest.raises(BpgError) as e:
+        gbe.g.SonnyRistrettoPointGadget.from_lcs(gp, 4, p)
+    assert e.value.code in (_native.EMISSING, _native.EGADGET)
+    # the same calls on a verifier allocate unassigned multipliers
+    v = gbe.Verifier(b"missing")
+    v.allocate_multiplier(None)
+    gbe.g.SonnyRistrettoPointGadget.from_lcs(gp, 4, v)
