@@ -172,7 +172,7 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
         t0 = time.perf_counter()
         one(b"lat%d" % verify, verify)
         lat.append((time.perf_counter() - t0) * 1e3)
-    secs = []
+    secs, cpu = [], []
     for verify in (False, True, "batch"):
         errs = []
 
@@ -186,13 +186,14 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
                 errs.append(repr(e))
         for warm in (True, False):                     # first pass: every thread's lane allocates its workspace
             th = [threading.Thread(target=worker, args=(t, warm)) for t in range(threads)]
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             [t.start() for t in th]
             [t.join() for t in th]
-            dt = time.perf_counter() - t0
+            dt, dc = time.perf_counter() - t0, time.process_time() - c0
             assert not errs, errs
         secs.append(dt)
-    return threads * per_thread, secs, lat, first
+        cpu.append(dc)                                 # host CPU seconds of the whole process (all threads) in the timed pass
+    return threads * per_thread, secs, lat, first, cpu
 
 
 def proof_cpu_baseline(nbits=PROOF_BITS):
@@ -240,7 +241,7 @@ def main():
     ap.add_argument("--logn", type=int, default=int(os.environ.get("BPG_BENCH_LOGN", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
-    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "24")))
+    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "32")))
     ap.add_argument("--proofs-per-thread", type=int, default=32, help="per host thread, in calls of --proofs-per-call (long enough for the threads to fall out of step: host and GPU phases of different threads then overlap)")
     ap.add_argument("--proofs-per-call", type=int, default=8, help="statements per bpg_prover_prove_many call (1: plain prove calls)")
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
@@ -406,7 +407,7 @@ def main():
     proofs = None
     if not args.no_proofs:
         barrier()
-        cnt, secs, lat, first_proof = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread, max(1, args.proofs_per_call))
+        cnt, secs, lat, first_proof, cpu_s3 = proof_bench(ctx, rank, args.proof_threads, args.proofs_per_thread, max(1, args.proofs_per_call))
         barrier()
         if world > 1:
             tt = torch.tensor(secs, dtype=torch.float64, device=cdev)
@@ -419,6 +420,9 @@ def main():
                   "multipliers": 27 * PROOF_BITS + 4, "proof_bytes": len(first_proof.to_bytes()),
                   "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt, "proofs_per_call": args.proofs_per_call,
                   "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
+                  "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0] / cnt, "prove_and_verify": 1e3 * cpu_s3[1] / cnt,
+                                            "note": "process CPU time (all host threads, spinning on stream synchronisation included) "
+                                                    "of this rank's timed pass / proofs; the box gives a rank 16 cores"},
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
                               "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}
 

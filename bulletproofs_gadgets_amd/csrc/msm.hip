@@ -1366,11 +1366,15 @@ static void msm_enqueue_accumulate(hipStream_t s, const msm_plan &pl, const msm_
                                    const seg_map &map, bool multi, uint32_t wstride, hipEvent_t ev_start = nullptr,
                                    hipEvent_t ev_stop = nullptr) {
     const dim3 grid((unsigned)((g.cap_lv[0] + 255) / 256));
+    static const size_t acc_lds = [] {
+        const char *e = getenv("BPG_ACC_LDS");
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
     if (multi)
-        hipExtLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
+        hipExtLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), acc_lds, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
                               y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
     else
-        hipExtLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), 0, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
+        hipExtLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), acc_lds, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
                               y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
 }
 
