@@ -207,7 +207,8 @@ class TranscriptRng:
     def scalars(self, n):
         out = ctypes.create_string_buffer(32 * max(n, 1))
         self.orc.lib.merlin_rng_scalars(self.st, out, ctypes.c_size_t(n))
-        return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+        raw = out.raw                      # one copy (out.raw copies the whole buffer every time it is read)
+        return [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(n)]
 
 
 class SeededRng:
