@@ -220,6 +220,24 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
 
 constexpr int SORT_U = 8;
 
+// Level-1 output item: (entry, bucket number within its bin).  A variable-base MSM of at most 2^23 points packs it
+// into one word -- point index (23 bits) | bucket in bin (8 bits) | sign -- which takes a third off the sort's
+// traffic (the item is written once and read twice); otherwise it is a pair of words.
+template <bool PACKED> struct sort_item;
+template <> struct sort_item<false> {
+    using T = uint2;
+    static __device__ __forceinline__ T make(uint32_t entry, uint32_t low) { return make_uint2(entry, low); }
+    static __device__ __forceinline__ uint32_t low(const T &t) { return t.y; }
+    static __device__ __forceinline__ uint32_t entry(const T &t) { return t.x; }
+};
+template <> struct sort_item<true> {
+    using T = uint32_t;
+    static __device__ __forceinline__ T make(uint32_t entry, uint32_t low) { return entry | (low << 23); }
+    static __device__ __forceinline__ uint32_t low(const T &t) { return (t >> 23) & 0xffu; }
+    static __device__ __forceinline__ uint32_t entry(const T &t) { return t & 0x807fffffu; }
+};
+constexpr size_t SORT_PACK_MAX_POINTS = (size_t)1 << 23;
+
 // LDS cursor increment, aggregated when every active lane of the wave asks for the same counter
 // (skewed digits: bit witnesses send a whole tile to one bin / one bucket; 64 lanes hammering
 // one LDS address serialise).  Returns the lane's slot (old counter value + its rank among the
@@ -326,9 +344,10 @@ __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t *__restrict__ 
 // level 1: entries -> bins.  tmp[pos] = (entry, bucket number within the bin); entry = scalar
 // index | sign << 31 (fixed-base mode: also the window << 26, i.e. which block of the shifted
 // table the point comes from)
+template <bool PACKED>
 __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ bin_off,
-                                                     uint32_t *__restrict__ bin_fill, uint2 *__restrict__ tmp, size_t n, int W,
-                                                     int NBIN, int lowshift, int tile, int shared) {
+                                                     uint32_t *__restrict__ bin_fill, typename sort_item<PACKED>::T *__restrict__ tmp,
+                                                     size_t n, int W, int NBIN, int lowshift, int tile, int shared) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, t = blockIdx.z;
     const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
@@ -370,7 +389,7 @@ __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__
             const size_t i = i0 + (size_t)u * blockDim.x;
             const uint32_t bk = (uint32_t)(d[u] < 0 ? -d[u] : d[u]) - 1u;
             const uint32_t pos = lds_claim(lds, bk >> lowshift, d[u] != 0);
-            if (d[u] != 0) tmp[pos] = make_uint2((uint32_t)i | wtag | (d[u] < 0 ? 0x80000000u : 0u), bk & lowmask);
+            if (d[u] != 0) tmp[pos] = sort_item<PACKED>::make((uint32_t)i | wtag | (d[u] < 0 ? 0x80000000u : 0u), bk & lowmask);
         }
     }
 }
@@ -399,8 +418,9 @@ __device__ __forceinline__ bool chunk_range(const uint32_t *__restrict__ bin_off
 // level 2a: one block per chunk counts the chunk's items per bucket of its bin: chunk_hist[c][LOWN].
 // A bin that is a single chunk (every bin, when the digits are uniform) is finished here: counts[g],
 // ent_off[g], entries sorted by bucket; 2b and 2c then skip it.
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_chunk_count(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
-                                                     const uint2 *__restrict__ tmp, uint32_t *__restrict__ chunk_hist,
+                                                     const typename sort_item<PACKED>::T *__restrict__ tmp, uint32_t *__restrict__ chunk_hist,
                                                      uint32_t *__restrict__ counts, uint32_t *__restrict__ ent_off,
                                                      uint32_t *__restrict__ entries, uint32_t nbt, uint32_t CH, int LOWN) {
     __shared__ uint32_t cnt[256], cur[256];
@@ -415,7 +435,7 @@ __global__ void __launch_bounds__(256) k_chunk_count(const uint32_t *__restrict_
 #pragma unroll
         for (int u = 0; u < SORT_U; u++) {
             const uint32_t i = i0 + 256u * u;
-            b[u] = i < hi ? tmp[i].y : 0xffffffffu;
+            b[u] = i < hi ? sort_item<PACKED>::low(tmp[i]) : 0xffffffffu;
         }
 #pragma unroll
         for (int u = 0; u < SORT_U; u++) (void)lds_claim(cnt, b[u], b[u] != 0xffffffffu);
@@ -447,16 +467,22 @@ __global__ void __launch_bounds__(256) k_chunk_count(const uint32_t *__restrict_
     }
     __syncthreads();
     for (uint32_t i0 = lo + tid; i0 < hi; i0 += 256u * SORT_U) {
-        uint2 it[SORT_U];
+        uint32_t lw[SORT_U], en[SORT_U];
 #pragma unroll
         for (int u = 0; u < SORT_U; u++) {
             const uint32_t i = i0 + 256u * u;
-            it[u] = i < hi ? tmp[i] : make_uint2(0u, 0xffffffffu);
+            lw[u] = 0xffffffffu;
+            en[u] = 0u;
+            if (i < hi) {
+                const typename sort_item<PACKED>::T t = tmp[i];
+                lw[u] = sort_item<PACKED>::low(t);
+                en[u] = sort_item<PACKED>::entry(t);
+            }
         }
 #pragma unroll
         for (int u = 0; u < SORT_U; u++) {
-            const uint32_t pos = lds_claim(cur, it[u].y, it[u].y != 0xffffffffu);
-            if (it[u].y != 0xffffffffu) entries[pos] = it[u].x;
+            const uint32_t pos = lds_claim(cur, lw[u], lw[u] != 0xffffffffu);
+            if (lw[u] != 0xffffffffu) entries[pos] = en[u];
         }
     }
 }
@@ -507,8 +533,9 @@ __global__ void __launch_bounds__(256) k_chunk_offsets(const uint32_t *__restric
 }
 
 // level 2c: one block per chunk places the chunk's entries: entries sorted by bucket
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_chunk_place(const uint32_t *__restrict__ bin_off, const uint32_t *__restrict__ chunk_off,
-                                                     const uint2 *__restrict__ tmp, const uint32_t *__restrict__ chunk_hist,
+                                                     const typename sort_item<PACKED>::T *__restrict__ tmp, const uint32_t *__restrict__ chunk_hist,
                                                      const uint32_t *__restrict__ ent_off, uint32_t *__restrict__ entries,
                                                      uint32_t nbt, uint32_t CH, int LOWN) {
     __shared__ uint32_t cur[256];
@@ -522,16 +549,22 @@ __global__ void __launch_bounds__(256) k_chunk_place(const uint32_t *__restrict_
         cur[tid] = tid < LOWN ? ent_off[(size_t)bin * LOWN + tid] + chunk_hist[(size_t)c * LOWN + tid] : 0u;
         __syncthreads();
         for (uint32_t i0 = lo + tid; i0 < hi; i0 += 256u * SORT_U) {
-            uint2 it[SORT_U];
+            uint32_t lw[SORT_U], en[SORT_U];
 #pragma unroll
             for (int u = 0; u < SORT_U; u++) {
                 const uint32_t i = i0 + 256u * u;
-                it[u] = i < hi ? tmp[i] : make_uint2(0u, 0xffffffffu);
+                lw[u] = 0xffffffffu;
+                en[u] = 0u;
+                if (i < hi) {
+                    const typename sort_item<PACKED>::T t = tmp[i];
+                    lw[u] = sort_item<PACKED>::low(t);
+                    en[u] = sort_item<PACKED>::entry(t);
+                }
             }
 #pragma unroll
             for (int u = 0; u < SORT_U; u++) {
-                const uint32_t pos = lds_claim(cur, it[u].y, it[u].y != 0xffffffffu);
-                if (it[u].y != 0xffffffffu) entries[pos] = it[u].x;
+                const uint32_t pos = lds_claim(cur, lw[u], lw[u] != 0xffffffffu);
+                if (lw[u] != 0xffffffffu) entries[pos] = en[u];
             }
         }
         __syncthreads();                                   // cur is reused
@@ -1239,7 +1272,7 @@ struct msm_geom {
 struct msm_bufs {
     int16_t *digits;
     uint32_t *entries, *counts;
-    uint2 *tmp;
+    void *tmp;                 // level-1 items: uint2 each, or one packed word each (sort_item)
     ge_rec *partials, *chunk, *out;
 };
 struct msm_maps {
@@ -1342,15 +1375,28 @@ static void msm_enqueue_sort(hipStream_t s, const msm_plan &pl, const msm_geom &
     const size_t bin_lds = (size_t)pl.nbin * sizeof(uint32_t);
     hipLaunchKernelGGL(k_bin_hist, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_counts, n, pl.W, pl.nbin, pl.lowshift, pl.tile, shared);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, y.bin_counts, y.bin_off, y.chunk_off, (uint32_t)g.NBT, g.CH);
-    hipLaunchKernelGGL(k_bin_scatter, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_off, y.bin_fill, b.tmp, n, pl.W, pl.nbin,
-                       pl.lowshift, pl.tile, shared);
-    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)g.NCH), dim3(256), 0, s, y.bin_off, y.chunk_off, b.tmp, y.chunk_hist, y.counts,
-                       y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    const bool packed = !shared && n <= SORT_PACK_MAX_POINTS && g.LOWN <= 256;
+    const dim3 place_grid((unsigned)(g.NCH < 2048 ? g.NCH : 2048));
+    if (packed) {
+        hipLaunchKernelGGL(k_bin_scatter<true>, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_off, y.bin_fill, (uint32_t *)b.tmp, n, pl.W,
+                           pl.nbin, pl.lowshift, pl.tile, shared);
+        hipLaunchKernelGGL(k_chunk_count<true>, dim3((unsigned)g.NCH), dim3(256), 0, s, y.bin_off, y.chunk_off, (const uint32_t *)b.tmp,
+                           y.chunk_hist, y.counts, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    } else {
+        hipLaunchKernelGGL(k_bin_scatter<false>, tgrid, dim3(512), bin_lds, s, b.digits, y.bin_off, y.bin_fill, (uint2 *)b.tmp, n, pl.W,
+                           pl.nbin, pl.lowshift, pl.tile, shared);
+        hipLaunchKernelGGL(k_chunk_count<false>, dim3((unsigned)g.NCH), dim3(256), 0, s, y.bin_off, y.chunk_off, (const uint2 *)b.tmp,
+                           y.chunk_hist, y.counts, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    }
     // (2b and 2c have work only when some bin is larger than a chunk: modest grids that stride)
     hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(g.NBT < 512 ? g.NBT : 512)), dim3(256), 0, s, y.bin_off, y.chunk_off,
                        y.chunk_hist, y.counts, y.ent_off, (uint32_t)g.NBT, g.LOWN);
-    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(g.NCH < 2048 ? g.NCH : 2048)), dim3(256), 0, s, y.bin_off, y.chunk_off, b.tmp,
-                       y.chunk_hist, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    if (packed)
+        hipLaunchKernelGGL(k_chunk_place<true>, place_grid, dim3(256), 0, s, y.bin_off, y.chunk_off, (const uint32_t *)b.tmp,
+                           y.chunk_hist, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
+    else
+        hipLaunchKernelGGL(k_chunk_place<false>, place_grid, dim3(256), 0, s, y.bin_off, y.chunk_off, (const uint2 *)b.tmp,
+                           y.chunk_hist, y.ent_off, b.entries, (uint32_t)g.NBT, g.CH, g.LOWN);
     // thread offsets of every pass (levels 0..R), two launches
     hipLaunchKernelGGL(k_scan_a, dim3((unsigned)g.nblk), dim3(256), 0, s, y.counts, y.lvl_base, g.lvl_words, g.NE, g.nlevels + 1,
                        pl.ls0, pl.ls1);
@@ -1464,7 +1510,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         BPG_CHECK_HIP(hipMemcpyAsync(j->d_stage, d_scalars, (size_t)T * n * 32, hipMemcpyHostToDevice, s));
         d_sc = (const uint32_t *)j->d_stage;
     }
-    const msm_bufs b{j->d_digits, j->d_entries, j->d_counts, (uint2 *)j->d_tmp, j->d_partials, j->d_chunk, j->d_out};
+    const msm_bufs b{j->d_digits, j->d_entries, j->d_counts, j->d_tmp, j->d_partials, j->d_chunk, j->d_out};
     const msm_layout y = msm_lay_out(g, b);
     msm_enqueue_sort(s, pl, g, b, y, d_sc, n, T, mm.smap, fb.c ? 1 : 0);
     // Accumulate passes of one lane's jobs run one after another: two of them at once only time-slice the
@@ -1571,7 +1617,7 @@ int msm_noalloc(bpg_ctx *ctx, const msm_seg *seg, const void *d_scalars, size_t 
     b.digits = (int16_t *)take(g.b_digits);
     b.entries = (uint32_t *)take(g.b_entries);
     b.counts = (uint32_t *)take(g.b_counts);
-    b.tmp = (uint2 *)take(g.b_tmp);
+    b.tmp = take(g.b_tmp);
     b.partials = (ge_rec *)take(g.b_partials);
     b.chunk = (ge_rec *)take(g.b_chunk);
     b.out = (ge_rec *)take(g.b_out);
@@ -1684,11 +1730,11 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, chunk_off, (uint32_t)NBT, CH);
     hipLaunchKernelGGL(k_fold_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, W, (uint32_t)np,
                        (uint32_t)m, tile);
-    hipLaunchKernelGGL(k_chunk_count, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
+    hipLaunchKernelGGL(k_chunk_count<false>, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
                        j->d_entries, (uint32_t)NBT, CH, LOWN);
     hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(NBT < 512 ? NBT : 512)), dim3(256), 0, s, bin_off, chunk_off, chunk_hist, counts,
                        ent_off, (uint32_t)NBT, LOWN);
-    hipLaunchKernelGGL(k_chunk_place, dim3((unsigned)(NCH < 2048 ? NCH : 2048)), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist,
+    hipLaunchKernelGGL(k_chunk_place<false>, dim3((unsigned)(NCH < 2048 ? NCH : 2048)), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist,
                        ent_off, j->d_entries, (uint32_t)NBT, CH, LOWN);
     hipLaunchKernelGGL(k_scan_a, dim3((unsigned)nblk), dim3(256), 0, s, counts, lvl_base, lvl_words, NE, nlevels + 1, S0, LS1);
     hipLaunchKernelGGL(k_scan_b, dim3(nlevels + 1), dim3(1024), 0, s, lvl_base, lvl_words, NE, nblk);
