@@ -281,7 +281,7 @@ class Prover(_CS):
         self._raise_callback_error()
         check(rc)
         rng.check()
-        return Proof(out.raw[:n.value])
+        return Proof(ctypes.string_at(out, n.value))
 
     @staticmethod
     def prove_many(provers, external_rng=None):
@@ -298,7 +298,8 @@ class Prover(_CS):
             p._raise_callback_error()
         check(rc)
         rng.check()
-        return [Proof(out.raw[j * cap:j * cap + lens[j]]) for j in range(k)]
+        base = ctypes.addressof(out)           # (out.raw would copy all k * cap bytes once per proof)
+        return [Proof(ctypes.string_at(base + j * cap, lens[j])) for j in range(k)]
 
     def stats(self):
         a, b = ctypes.c_size_t(), ctypes.c_size_t()
