@@ -168,3 +168,22 @@ def test_sharded_prove_many(gpu_ctx):
         return [p.to_bytes() for p in g.Prover.prove_many([build(be, *w) for w in wit], ext)]
     for got in run_ranks(gpu_ctx, 2, fn):
         assert got == want
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_two_phase_proof(gpu_ctx, oracle, world):
+    """randomized (two-phase) constraints over sharded generators: the first- and second-phase commitments are MSMs
+    over sub-ranges [0, n1) and [n1, n) of G / H that cut across the ranks' ranges; bytes = the oracle's"""
+    import random
+    rnd = random.Random(99)
+    L = sonny.L
+    xs = [rnd.randrange(L) for _ in range(9)]
+    perm = xs[3:] + xs[:3]
+    want_ok, want = rc.shuffle_roundtrip(OracleBackend(oracle), xs, perm, first_phase_squares=5, rng=R.SeededRng(b"sh2p"), cap=64)
+    assert want_ok
+
+    def fn(be):
+        ok, proof = rc.shuffle_roundtrip(be, xs, perm, first_phase_squares=5, rng=R.SeededRng(b"sh2p"), cap=64)
+        return ok, proof.to_bytes()
+    for ok, raw in run_ranks(gpu_ctx, world, fn):
+        assert ok and raw == want.to_bytes()

@@ -24,7 +24,7 @@ def main():
     def work(tid):
         rows = []
         for rep in range(3):
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.thread_time()
             ps, ext = [], b""
             for j in range(k):
                 bl, ext_p, _ = randomness(b"%d-%d-%d" % (tid, rep, j))
@@ -33,14 +33,15 @@ def main():
                 E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
                 ps.append(p)
                 ext += ext_p
-            t1 = time.perf_counter()
+            t1, c1 = time.perf_counter(), time.thread_time()
             if k == 1:
                 ps[0].prove(gens, ext)
             else:
                 g.Prover.prove_many(ps, ext)
-            t2 = time.perf_counter()
+            t2, c2 = time.perf_counter(), time.thread_time()
             tm = [p.timing() for p in ps]
             rows.append({"capture_ms_per_proof": round((t1 - t0) * 1e3 / k, 2), "prove_ms_per_proof": round((t2 - t1) * 1e3 / k, 2),
+                         "capture_cpu_ms_per_proof": round((c1 - c0) * 1e3 / k, 2), "prove_cpu_ms_per_proof": round((c2 - c1) * 1e3 / k, 2),
                          "rng_ms": round(sum(t["rng_ms"] for t in tm) / k, 2), "commit_ms": round(sum(t["commit_ms"] for t in tm) / k, 2),
                          "poly_ms": round(sum(t["poly_ms"] for t in tm) / k, 2), "ipp_ms": round(sum(t["ipp_ms"] for t in tm) / k, 2)})
         res[tid] = rows[-1]
