@@ -108,7 +108,7 @@ __device__ void lds_bit_tree(uint32_t *lds, int nslots, int nodes, int per, int 
                 ge a, b;
                 lds_get(a, lds, nslots, L * per + j);
                 lds_get(b, lds, nslots, R * per + j);
-                ge_add(o, a, b);
+                ge_add(o, a, b);               // (hot25519's gez_add here: 140 B of spills, 110 -> 124 us)
             } else {
                 lds_get(o, lds, nslots, R * per);
             }
@@ -841,12 +841,14 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t *__restrict__ cou
     uint32_t in0 = prev.local[g] + prev.base[g >> 10];
     uint32_t lo = rank << ls1, hi = lo + (1u << ls1);
     hi = hi < kprev ? hi : kprev;
+    fe_zeros Zr;
+    fe_zeros_init(Zr);
     ge acc;
     load_ge(acc, parts_in + in0 + lo);
     for (uint32_t i = lo + 1; i < hi; i++) {
         ge b;
         load_ge(b, parts_in + in0 + i);
-        ge_add(acc, acc, b);
+        gez_add(acc, acc, b, Zr);
     }
     store_ge(parts_out + t, acc);
 }
