@@ -2,7 +2,7 @@
 set -e
 O=gpurun_out/ls0
 mkdir -p $O
-for v in 16 24 32 48 64; do
+for v in ${LS0_LIST:-16 24 32 48 64}; do
   BPG_MSM_LS0=$v timeout -k 10 120 python3 bench.py --no-proofs --no-big-proof --no-batch --no-cpu-baseline --no-extras > $O/ls0_$v.json 2> $O/ls0_$v.err
   python3 -c "
 import json,sys
