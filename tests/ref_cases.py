@@ -270,3 +270,27 @@ def shuffle_roundtrip(be, inputs, outputs, first_phase_squares=0, rng=None, cap=
         shuffle_gadget(v, vv[:k], vv[k:])
         v.verify(proof, be.pc_gens, bp, rng.fill_bytes(32))
     return _ok(verify, be), proof
+
+
+# ---- edge: circuits with no multiplier (n = 0, padded to 1: an inner-product argument of zero rounds) and with one
+def linear_only_roundtrip(be, a, b, total, n_mult=0, rng=None, cap=4):
+    """commits a, b and proves a + b = total with linear constraints only (n_mult = 0), or also a * b = ab (n_mult = 1)"""
+    rng = rng or SeededRng(b"lin")
+    bp = be.bp_gens(cap)
+
+    def circuit(cs, va, vb):
+        cs.constrain(va + vb - total)
+        for _ in range(n_mult):
+            _, _, o = cs.multiply(va + 0, vb + 0)
+            cs.constrain(o - (a * b))
+    prover = be.Prover(be.Transcript(b"Linear"))
+    Va, va = prover.commit(a, rng.scalar())
+    Vb, vb = prover.commit(b, rng.scalar())
+    circuit(prover, va, vb)
+    proof = prover.prove(bp, rng.fill_bytes(32))
+
+    def verify():
+        v = be.Verifier(be.Transcript(b"Linear"))
+        circuit(v, v.commit(Va), v.commit(Vb))
+        v.verify(proof, be.pc_gens, bp, rng.fill_bytes(32))
+    return _ok(verify, be), proof

@@ -196,3 +196,13 @@ def test_challenge_scalar_outside_the_randomization_phase(be):
     p = be.Prover(be.Transcript(b"x"))
     with pytest.raises(R.R1CSError):
         p.challenge_scalar(b"c")
+
+
+def test_circuits_without_multipliers(be):
+    """n = 0 pads to one multiplier slot and an inner-product argument of zero rounds (bulletproofs: padded_n = 1)"""
+    ok, proof = rc.linear_only_roundtrip(be, 5, 7, 12)
+    assert ok and len(proof.ipp.L_vec) == 0
+    assert not rc.linear_only_roundtrip(be, 5, 7, 13)[0]
+    ok, proof = rc.linear_only_roundtrip(be, 5, 7, 12, n_mult=1)
+    assert ok and len(proof.ipp.L_vec) == 0
+    assert rc.linear_only_roundtrip(be, 5, 7, 12, n_mult=3)[0]

@@ -532,3 +532,10 @@ def test_missing_assignment(gbe):
     v = gbe.Verifier(b"missing")
     v.allocate_multiplier(None)
     gbe.g.SonnyRistrettoPointGadget.from_lcs(gp, 4, v)
+
+
+def test_circuits_without_multipliers(gbe, obe):
+    """edge sizes: no multiplier at all (n = 0 -> padded to 1, zero inner-product rounds), one, three (padded to 4)"""
+    for n_mult in (0, 1, 3):
+        assert _both(rc.linear_only_roundtrip, gbe, obe, 5, 7, 12, n_mult=n_mult)
+        assert not _both(rc.linear_only_roundtrip, gbe, obe, 5, 7, 13, n_mult=n_mult)
