@@ -1571,12 +1571,18 @@ __global__ void __launch_bounds__(64) k_tail_final(const ge_rec *__restrict__ se
     }
     __syncthreads();
     if (w != 0) return;
+    // Everything below depends on wave-uniform values only (lane 0, LDS addresses without a lane term), and the
+    // compiler then selects the whole chain of field arithmetic for the scalar unit and spends seven minutes in
+    // "SI Fix SGPR copies" moving it back to the vector unit.  An offset it cannot see through (always zero, in a
+    // VGPR) makes the loads, and with them the arithmetic, per-lane from the start.
+    int lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     ge acc, t;
     ge_identity(acc);
     for (int k = Wb - 1; k >= 0; k--) {
         if (k != Wb - 1)
             for (int d = 0; d < C; d++) ge_double(acc, acc);
-        load_ge(t, &v[k]);
+        load_ge(t, &v[k + lane_zero]);
         ge_add(acc, acc, t);
     }
     uint32_t enc[8];
