@@ -17,14 +17,15 @@ objs=()
 pids=()
 for f in ${SRC}/*.hip; do
     o=build/$(basename "${f%.hip}").o
-    if [[ ! -f $o || $f -nt $o || -n $(find ${SRC} include -name '*.h' -newer "$o" -print -quit) ]]; then
+    # headers and the generated instruction stream (madd_gfx950.inc, included from hot25519.h) are dependencies of every object
+    if [[ ! -f $o || $f -nt $o || -n $(find ${SRC} include \( -name '*.h' -o -name '*.inc' \) -newer "$o" -print -quit) ]]; then
         echo "hipcc $f"
         ( $HIPCC $HIPFLAGS -c "$f" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
         pids+=($!)
     fi
     objs+=("$o")
 done
-for p in "${pids[@]}"; do wait "$p"; done      # a failed compile stops the build (set -e): never link a stale object
+for p in ${pids[@]+"${pids[@]}"}; do wait "$p"; done      # a failed compile stops the build (set -e): never link a stale object
 $HIPCC -shared -fPIC --offload-arch=${ARCH} -o ${OUT}/libbpg.so "${objs[@]}" -Wl,-rpath,/opt/rocm/lib -lpthread
 echo "built ${OUT}/libbpg.so"
 
@@ -33,3 +34,10 @@ echo "built oracle/liboracle.so"
 
 $HIPCC -O2 -std=c++17 -fPIC --offload-arch=${ARCH} -shared -o tests/native/libhost_hooks.so tests/native/host_hooks.hip -Wl,-rpath,/opt/rocm/lib
 echo "built tests/native/libhost_hooks.so"
+
+# measurement tools (tools/*.hip): built on request, never committed
+if [[ "${BPG_BUILD_TOOLS:-0}" == "1" ]]; then
+    $HIPCC -O3 --offload-arch=${ARCH} tools/irate.hip -o tools/irate
+    $HIPCC -O3 --offload-arch=${ARCH} tools/ubench.hip -o tools/ubench
+    echo "built tools/irate tools/ubench"
+fi

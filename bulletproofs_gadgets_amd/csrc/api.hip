@@ -325,6 +325,8 @@ void bpg_shutdown(bpg_ctx *ctx) {
         if (lane->ws) (void)hipFree(lane->ws);
         if (lane->d_dyn) (void)hipFree(lane->d_dyn);
         if (lane->d_io) (void)hipFree(lane->d_io);
+        if (lane->d_vacc) (void)hipFree(lane->d_vacc);
+        if (lane->d_vtail) (void)hipFree(lane->d_vtail);
         (void)hipStreamDestroy(lane->stream);
         delete lane;
     }

@@ -131,6 +131,12 @@ struct bpg_lane {
     // per call: hipFree is a device-wide synchronisation, and 24 prover threads share the GPU)
     void *d_io = nullptr;
     size_t io_cap = 0;
+    // batch verification: the accumulated generator scalars (2 x capacity) and the per-proof point scalars of the
+    // combined equation.  They outlive the per-proof passes over the arena above, so they have their own buffers.
+    void *d_vacc = nullptr;
+    size_t vacc_cap = 0;
+    void *d_vtail = nullptr;
+    size_t vtail_cap = 0;
 };
 
 struct bpg_ctx {

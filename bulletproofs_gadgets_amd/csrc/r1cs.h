@@ -271,7 +271,12 @@ class Prover : public ConstraintSystem {
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, a_L_.size(), v_.size()); }
     bool is_prover() const override { return true; }
-    void specify_randomized_constraints(RandomizedFn cb) override { deferred_.push_back(std::move(cb)); }
+    // (upstream's types make a registration from inside a callback impossible: the rcs handed to a callback is not
+    // randomizable.  Here the handle is the same object, so the second phase refuses it instead of dropping it.)
+    void specify_randomized_constraints(RandomizedFn cb) override {
+        if (phase2_) throw R1CSError(BPG_EINVAL, "specify_randomized_constraints inside a randomized-constraints callback");
+        deferred_.push_back(std::move(cb));
+    }
     Scalar challenge_scalar(const std::string &label) override;
     // Prover::prove(&bp_gens) names the generators at proving time: a prover made against one generator object
     // (whose Pedersen bases every object shares) may prove against another of the same context
@@ -301,6 +306,7 @@ class Prover : public ConstraintSystem {
     int commit3(size_t lo, size_t hi, const sc bl[3], const sc *sL, const sc *sR, uint8_t out96[96]);
     std::vector<RandomizedFn> deferred_;
     bool phase2_ = false, two_phase_done_ = false;
+    bool consumed_ = false;               // a two-phase prove() has run its callbacks: they cannot run again (upstream: prove(self))
     size_t n1_ = 0;                       // multipliers of the first phase (all of them without randomized constraints)
     sc i_bl2_, o_bl2_, s_bl2_;            // second-phase blindings (zero without a second phase)
     Gens *gens_;
@@ -337,7 +343,10 @@ class Verifier : public ConstraintSystem {
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, num_vars_, V_.size() / 32); }
     bool is_prover() const override { return false; }
-    void specify_randomized_constraints(RandomizedFn cb) override { deferred_.push_back(std::move(cb)); }
+    void specify_randomized_constraints(RandomizedFn cb) override {
+        if (phase2_) throw R1CSError(BPG_EINVAL, "specify_randomized_constraints inside a randomized-constraints callback");
+        deferred_.push_back(std::move(cb));
+    }
     Scalar challenge_scalar(const std::string &label) override;
     // Verifier::verify(&proof, &pc_gens, &bp_gens, &mut rng); BPG_OK or BPG_EVERIFY / BPG_EGENS / ...
     int verify(const R1CSProof &proof, Gens *gens, rng_fill_fn rng, void *rng_user);

@@ -1050,6 +1050,7 @@ int Prover::two_phase_prologue(R1CSProof &P) {
     tr_.r1cs_2phase_domain_sep();
     std::vector<RandomizedFn> cbs;
     cbs.swap(deferred_);
+    consumed_ = true;
     phase2_ = true;
     try {
         for (auto &cb : cbs) cb(*this);
@@ -1103,6 +1104,10 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
 int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
     t_start_ = now_ms();
     const size_t n = a_L_.size(), m = v_.size();
+    if (consumed_) {
+        set_last_error_msg("prove: this prover's randomized-constraint callbacks have already run (a prover proves once)");
+        return BPG_EINVAL;
+    }
     if (gens_->capacity < next_pow2(n ? n : 1)) return BPG_EGENS;
     tr_.append_u64("m", m);
     rng_.reset(new TranscriptRng(tr_.build_rng()));
@@ -1229,6 +1234,20 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         ps[j]->n1_ = ps[j]->a_L_.size();
         ps[j]->i_bl2_ = ps[j]->o_bl2_ = ps[j]->s_bl2_ = sc_zero();
     }
+    // Two-phase state is per prove() call: whatever path leaves this function (a failed allocation, exchange or HIP
+    // call included), a later prove() on the same prover starts from a clean slate instead of skipping the A / S
+    // commitments of a prologue that belongs to this call.
+    struct PhaseReset {
+        Prover *const *ps;
+        size_t g;
+        ~PhaseReset() {
+            for (size_t j = 0; j < g; j++) {
+                ps[j]->two_phase_done_ = false;
+                ps[j]->n1_ = 0;
+                ps[j]->i_bl2_ = ps[j]->o_bl2_ = ps[j]->s_bl2_ = sc_zero();
+            }
+        }
+    } phase_reset{ps, g};
     if (!ps[0]->deferred_.empty()) {
         if (g != 1) return BPG_EINVAL;
         int rc2 = ps[0]->two_phase_prologue(out[0]);
@@ -1531,7 +1550,6 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         p.timing.ipp_ms = ipp_ms;
         p.timing.total_ms = t_end - p.t_start_;
         p.rng_.reset();
-        p.two_phase_done_ = false;
     }
     return BPG_OK;
 }
@@ -1772,15 +1790,11 @@ int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *g
     if (!lane) return BPG_EDEVICE;
     hipStream_t s = lane->stream;
     const size_t cap = gens->capacity;
-    sc *d_acc = nullptr, *d_tail = nullptr;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_acc, 2 * cap * 32));
-    struct Free {
-        sc *&a, *&b;
-        ~Free() {
-            if (a) (void)hipFree(a);
-            if (b) (void)hipFree(b);
-        }
-    } guard{d_acc, d_tail};
+    // the accumulators live in the lane (grown on demand, kept): no hipMalloc / hipFree per call -- hipFree is a
+    // device-wide synchronisation under every other thread that proves or verifies on this GPU
+    int rcg;
+    if ((rcg = grow(&lane->d_vacc, &lane->vacc_cap, 2 * cap * 32))) return rcg;
+    sc *d_acc = (sc *)lane->d_vacc;
     BPG_CHECK_HIP(hipMemsetAsync(d_acc, 0, 2 * cap * 32, s));
     std::vector<sc> tail(2);
     std::vector<uint8_t> dyn;
@@ -1807,7 +1821,8 @@ int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *g
     }
     tail[0] = accB.v;
     tail[1] = accBb.v;
-    BPG_CHECK_HIP(hipMalloc((void **)&d_tail, tail.size() * 32));
+    if ((rcg = grow(&lane->d_vtail, &lane->vtail_cap, tail.size() * 32))) return rcg;
+    sc *d_tail = (sc *)lane->d_vtail;
     // [g[0..cap) | h[0..np_max)]: g scalars beyond np_max are zero and produce no bucket entries
     return verify_msm(lane, gens, d_acc, cap, np_max, d_tail, tail, dyn);
 }

@@ -316,6 +316,17 @@ def test_verify_batch(gbe, obe, rnd):
     # a stream that runs out is an error, never zero padding
     with pytest.raises(ValueError):
         g.verify_batch(verifiers(), proofs, bp, ext[:32 * len(items) - 1])
+    # no device allocation on the hot verify path -- after the calls above have sized the lane's
+    # buffers, 100 more calls leave the free device memory where it was
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free0, free1, total = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    gbe.ctx.synchronize()
+    assert hip.hipMemGetInfo(ctypes.byref(free0), ctypes.byref(total)) == 0
+    for _ in range(100):
+        assert g.verify_batch(verifiers(), proofs, bp, ext)
+    assert hip.hipMemGetInfo(ctypes.byref(free1), ctypes.byref(total)) == 0
+    assert free1.value == free0.value
 
 
 def test_prove_many_equals_sequential_proves(gbe, rnd):

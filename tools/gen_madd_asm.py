@@ -469,6 +469,8 @@ def main():
     if "--check-only" not in sys.argv:
         import os
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bulletproofs_gadgets_amd", "csrc", "madd_gfx950.inc")
+        if "--out" in sys.argv:                  # tests/test_generated_stream.py: regenerate elsewhere and compare with the committed file
+            path = sys.argv[sys.argv.index("--out") + 1]
         print("wrote %s: %d instructions, %d v_mad_u64_u32, %d other VALU, %d s_nop" % ((path,) + emit(ops, order, path)))
 
 
