@@ -172,7 +172,7 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
         t0 = time.perf_counter()
         one(b"lat%d" % verify, verify)
         lat.append((time.perf_counter() - t0) * 1e3)
-    secs, cpu = [], []
+    secs, cpu, cpu_sys = [], [], []
     for verify in (False, True, "batch"):
         errs = []
 
@@ -193,14 +193,15 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
                 errs.append(repr(e))
         for warm in (True, False):                     # first pass: every thread's lane allocates its workspace
             th = [threading.Thread(target=worker, args=(t, warm)) for t in range(threads)]
-            t0, c0 = time.perf_counter(), time.process_time()
+            t0, c0, o0 = time.perf_counter(), time.process_time(), os.times()
             [t.start() for t in th]
             [t.join() for t in th]
-            dt, dc = time.perf_counter() - t0, time.process_time() - c0
+            dt, dc, o1 = time.perf_counter() - t0, time.process_time() - c0, os.times()
             assert not errs, errs
         secs.append(dt)
         cpu.append(dc)                                 # host CPU seconds of the whole process (all threads) in the timed pass
-    return threads * per_thread, secs, lat, first, cpu
+        cpu_sys.append(o1.system - o0.system)          # of which in the kernel (page faults, pinning, driver calls)
+    return threads * per_thread, secs, lat, first, (cpu, cpu_sys)
 
 
 def proof_cpu_baseline(nbits=PROOF_BITS):
@@ -427,7 +428,8 @@ def main():
                   "multipliers": 27 * PROOF_BITS + 4, "proof_bytes": len(first_proof.to_bytes()),
                   "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt, "proofs_per_call": args.proofs_per_call,
                   "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
-                  "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0] / cnt, "prove_and_verify": 1e3 * cpu_s3[1] / cnt,
+                  "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0][0] / cnt, "prove_and_verify": 1e3 * cpu_s3[0][1] / cnt,
+                                            "prove_kernel_mode": 1e3 * cpu_s3[1][0] / cnt,
                                             "note": "process CPU time (all host threads, spinning on stream synchronisation included) "
                                                     "of this rank's timed pass / proofs; the box gives a rank 16 cores"},
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "

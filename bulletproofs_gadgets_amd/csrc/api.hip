@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 
 #include "bpg_internal.h"
 
@@ -138,12 +139,91 @@ bpg_lane *lane_of(bpg_ctx *ctx) {
         delete lane;
         return nullptr;
     }
+    if (ctx->sync_block && ctx->sync_poll) {
+        e = hipEventCreateWithFlags(&lane->ev_sync, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            set_last_error("hipEventCreateWithFlags(lane)", e);
+            (void)hipStreamDestroy(lane->stream);
+            delete lane;
+            return nullptr;
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->lanes.push_back(lane);
     }
     cache.push_back({ctx->id, lane});
     return lane;
+}
+
+// ---- host-phase accounting (BPG_TRACE_HOST=1)
+static std::atomic<int> g_trace_host{-1};
+static std::atomic<uint64_t> g_phase_wall_us[HostPhase::N], g_phase_cpu_us[HostPhase::N], g_phase_calls[HostPhase::N];
+static double clock_ms(clockid_t id) {
+    struct timespec ts;
+    clock_gettime(id, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+bool HostPhase::enabled() {
+    int v = g_trace_host.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("BPG_TRACE_HOST");
+        v = e && *e && *e != '0';
+        g_trace_host.store(v);
+    }
+    return v != 0;
+}
+void HostPhase::add(Id id, double wall_ms, double cpu_ms) {
+    g_phase_wall_us[id] += (uint64_t)(wall_ms * 1e3);
+    g_phase_cpu_us[id] += (uint64_t)(cpu_ms * 1e3);
+    g_phase_calls[id]++;
+}
+HostPhase::HostPhase(Id i) : id(i), w0(0), c0(0), on(enabled()) {
+    if (on) {
+        w0 = clock_ms(CLOCK_MONOTONIC);
+        c0 = clock_ms(CLOCK_THREAD_CPUTIME_ID);
+    }
+}
+void HostPhase::stop() {
+    if (on) add(id, clock_ms(CLOCK_MONOTONIC) - w0, clock_ms(CLOCK_THREAD_CPUTIME_ID) - c0);
+    on = false;
+}
+void HostPhase::report() {
+    if (!enabled()) return;
+    static const char *names[N] = {"capture_commit", "rng_begin", "rng_draw", "upload", "as_submit", "as_wait", "flatten_poly", "t_commit",
+                                   "ipp_rows", "ipp_submit", "ipp_wait", "ipp_host", "fold", "tail_host"};
+    fprintf(stderr, "[bpg host phases] %-16s %10s %12s %12s\n", "phase", "calls", "wall_ms", "thread_cpu_ms");
+    for (int i = 0; i < N; i++)
+        fprintf(stderr, "[bpg host phases] %-16s %10llu %12.1f %12.1f\n", names[i], (unsigned long long)g_phase_calls[i].load(),
+                g_phase_wall_us[i].load() / 1e3, g_phase_cpu_us[i].load() / 1e3);
+}
+
+// Waiting without burning a core.  What makes the HIP runtime sleep in its waits is the DEVICE's scheduling flag
+// (hipDeviceScheduleBlockingSync), which bpg_init sets when it can; hipEventBlockingSync on an event alone still
+// spins in user mode (measured: 36.6 ms of thread CPU per 2^16 proof against 12.1 with the device flag).  When
+// another library has already fixed the device's flags (ctx->sync_poll), the wait polls the event itself: a short
+// spin for waits that are nearly over, then naps.  BPG_SYNC=spin: the runtime's busy wait (lowest latency for one
+// proof alone; a prover service runs more threads than cores, and a spinning waiter takes a core from a thread
+// that captures or draws).
+hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev) {
+    if (!ctx->sync_block || !ctx->sync_poll) return hipEventSynchronize(ev);
+    hipError_t e;
+    for (int spin = 0; spin < 200; spin++)
+        if ((e = hipEventQuery(ev)) != hipErrorNotReady) return e;
+    long ns = 20000;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
+        struct timespec ts = {0, ns};
+        nanosleep(&ts, nullptr);
+        if (ns < 100000) ns += 10000;
+    }
+    return e;
+}
+hipError_t lane_sync(bpg_lane *lane) {
+    const bpg_ctx *ctx = lane->ctx;
+    if (!ctx->sync_block || !ctx->sync_poll || !lane->ev_sync) return hipStreamSynchronize(lane->stream);
+    hipError_t e = hipEventRecord(lane->ev_sync, lane->stream);
+    if (e != hipSuccess) return e;
+    return wait_event(ctx, lane->ev_sync);
 }
 
 #define BPG_LANE(ctx)                    \
@@ -162,7 +242,7 @@ int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, si
     BPG_CHECK_HIP(hipMemcpyAsync(d_in, host64, n * 64, hipMemcpyHostToDevice, lane->stream));
     hipLaunchKernelGGL(k_from_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    BPG_CHECK_HIP(lane_sync(lane));
     return BPG_OK;
 }
 
@@ -179,7 +259,7 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n, d_flag);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(n_bad, d_flag, 4, hipMemcpyDeviceToHost, lane->stream));
-    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    BPG_CHECK_HIP(lane_sync(lane));
     return BPG_OK;
 }
 
@@ -246,7 +326,7 @@ int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int
     BPG_LANE(ctx);
     hipLaunchKernelGGL(k_shift_table, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, lane->stream, table, npts, c, W);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    BPG_CHECK_HIP(lane_sync(lane));
     return BPG_OK;
 }
 
@@ -281,11 +361,23 @@ int bpg_init(int device_id, bpg_ctx **out) {
         }
     }
     BPG_CHECK_HIP(hipSetDevice(device_id));
-    // BPG_SYNC=block: host threads sleep in stream / event waits instead of spinning (many prover
-    // threads per GPU share the host cores with circuit capture and the transcript's Keccak chain)
-    if (const char *s = getenv("BPG_SYNC"))
-        if (!strcmp(s, "block")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    // Host threads sleep in stream / event waits instead of spinning (many prover threads per GPU share the host
+    // cores with circuit capture and the transcript's Keccak chain); BPG_SYNC=spin restores the busy wait.
+    bool sync_block = true;
+    if (const char *s = getenv("BPG_SYNC")) sync_block = strcmp(s, "spin") != 0;
     bpg_ctx *ctx = new bpg_ctx();
+    ctx->sync_block = sync_block;
+    if (sync_block) {
+        const char *mode = getenv("BPG_SYNC");
+        unsigned flags = 0;
+        bool took = false;
+        if (!(mode && !strcmp(mode, "poll"))) {                       // BPG_SYNC=poll: the fallback below, on request (tests)
+            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // refused once the device is in use with other flags
+            (void)hipGetLastError();
+            took = hipGetDeviceFlags(&flags) == hipSuccess && (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync;
+        }
+        ctx->sync_poll = !took;
+    }
     ctx->device = device_id;
     ctx->id = g_next_ctx_id.fetch_add(1);
     {
@@ -313,20 +405,25 @@ int bpg_init(int device_id, bpg_ctx **out) {
 
 void bpg_shutdown(bpg_ctx *ctx) {
     if (!ctx) return;
+    HostPhase::report();
     (void)hipSetDevice(ctx->device);
     // no call may be in flight on any thread; lanes of threads that have exited are freed here too
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
     }
+    forget_shapes_of(ctx->id);
     for (auto *lane : ctx->lanes) {
         for (auto *j : lane->jobs) msm_job_destroy(j);
         (void)hipStreamSynchronize(lane->stream);
         if (lane->ws) (void)hipFree(lane->ws);
         if (lane->d_dyn) (void)hipFree(lane->d_dyn);
         if (lane->d_io) (void)hipFree(lane->d_io);
+        if (lane->h_raw) (void)hipHostFree(lane->h_raw);
+        if (lane->h_wit) (void)hipHostFree(lane->h_wit);
         if (lane->d_vacc) (void)hipFree(lane->d_vacc);
         if (lane->d_vtail) (void)hipFree(lane->d_vtail);
+        if (lane->ev_sync) (void)hipEventDestroy(lane->ev_sync);
         (void)hipStreamDestroy(lane->stream);
         delete lane;
     }
@@ -422,7 +519,7 @@ int bpg_points_compress(bpg_ctx *ctx, const bpg_points *pts, size_t start, size_
     hipLaunchKernelGGL(k_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, pts->d_table + start, d_out, n);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_out, n * 32, hipMemcpyDeviceToHost, lane->stream));
-    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    BPG_CHECK_HIP(lane_sync(lane));
     return BPG_OK;
 }
 

@@ -70,6 +70,8 @@ int fixed_base_window(size_t points);
 int fixed_base_windows(int c);
 
 int grow(void **p, size_t *cap, size_t need);
+// pinned host memory, same contract as grow() (BPG_OK or BPG_ENOMEM; the old contents are not kept)
+int grow_pinned(void **p, size_t *cap, size_t need);
 // hipMalloc behind the fault-injection hook of bpg_debug_fail_alloc (every growable workspace goes through it)
 hipError_t device_malloc(void **p, size_t bytes);
 void debug_fail_alloc(int countdown);
@@ -118,6 +120,7 @@ struct bpg_msm_job {
 struct bpg_lane {
     bpg_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;     // setup / codec / scalar-vector kernel stream
+    hipEvent_t ev_sync = nullptr;     // polled waits on `stream` (lane_sync); null unless ctx->sync_poll
     std::vector<bpg_msm_job *> jobs;  // MSM job pool (each job has its own stream)
     float last_acc_us = 0.f, last_total_us = 0.f;
     bpg_msm_job *acc_gate_job = nullptr;   // job whose accumulate pass was submitted last (its ev[2] gates the next one)
@@ -133,6 +136,14 @@ struct bpg_lane {
     size_t io_cap = 0;
     // batch verification: the accumulated generator scalars (2 x capacity) and the per-proof point scalars of the
     // combined equation.  They outlive the per-proof passes over the arena above, so they have their own buffers.
+    // pinned host staging (hipHostMalloc; grown on demand, kept): the blinding draws are written here as the RNG
+    // delivers them and the witness vectors are gathered here, so every large upload of a proof is a plain DMA.
+    // (hipMemcpyAsync from pageable memory goes through the runtime's own staging path: under 24 prover threads
+    // it cost 5 ms of CPU per 2^16 proof, most of it waiting inside the runtime.)
+    void *h_raw = nullptr;
+    size_t h_raw_cap = 0;
+    void *h_wit = nullptr;
+    size_t h_wit_cap = 0;
     void *d_vacc = nullptr;
     size_t vacc_cap = 0;
     void *d_vtail = nullptr;
@@ -144,6 +155,8 @@ struct bpg_ctx {
     uint64_t id = 0;                  // process-unique; keys the per-thread lane cache
     bpg::msm_tuning tune;
     int resident_lanes = 262144;      // CUs x 4 SIMDs x 4 waves x 64 lanes: threads of k_accumulate resident at once
+    bool sync_block = true;           // waits sleep instead of spinning; BPG_SYNC=spin clears it
+    bool sync_poll = false;           // the device's blocking-sync flag could not be set: waits poll and nap (api.hip: wait_event)
     std::mutex mu;                    // guards lanes, free_lanes
     std::vector<bpg_lane *> lanes;
     std::vector<bpg_lane *> free_lanes;   // lanes of threads that have exited: the next new thread takes one over
@@ -155,11 +168,30 @@ struct bpg_ctx {
     std::mutex flat_mu;
     std::vector<std::shared_ptr<void>> flat_cache;
     std::atomic<uint64_t> flat_hits{0}, flat_misses{0};
+    std::atomic<uint64_t> flat_followed{0};          // hits found by following the cached circuit during capture (no hash, no compare)
 };
 
 namespace bpg {
+// Host-phase accounting (BPG_TRACE_HOST=1; printed by bpg_shutdown): wall and thread-CPU time per named phase,
+// summed over all threads.  Where a prover thread's time goes under load cannot be read off a GPU trace.
+struct HostPhase {
+    enum Id { CAPTURE_COMMIT, RNG_BEGIN, RNG_DRAW, UPLOAD, AS_SUBMIT, AS_WAIT, FLATTEN_POLY, T_COMMIT, IPP_ROWS, IPP_SUBMIT, IPP_WAIT, IPP_HOST,
+              FOLD, TAIL_HOST, N };
+    static bool enabled();
+    static void add(Id id, double wall_ms, double cpu_ms);
+    static void report();
+    Id id;
+    double w0, c0;
+    bool on;
+    explicit HostPhase(Id i);
+    void stop();                       // account now (the destructor then does nothing)
+    ~HostPhase() { stop(); }
+};
 // the calling thread's lane of ctx (created on first use, device made current); nullptr on HIP failure
 bpg_lane *lane_of(bpg_ctx *ctx);
+// wait for the lane's stream (sleeping or spinning, per ctx->sync_block)
+hipError_t lane_sync(bpg_lane *lane);
+hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev);
 
 // One run of consecutive table records that an MSM reads; up to 4 per MSM, possibly from
 // different tables (generator table + a lane's per-proof points).
@@ -192,4 +224,5 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
 int msm_fold_wait(bpg_msm_job *job);
 int combine_partials(const uint8_t *ext128, size_t k, uint8_t out32[32]);
 void msm_job_destroy(bpg_msm_job *job);
+void forget_shapes_of(uint64_t ctx_id);
 }  // namespace bpg

@@ -779,8 +779,8 @@ template <bool MULTI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ ent_off,
              level_ref lv0, const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts, uint32_t nblk, int ls0, seg_map map,
-             uint32_t wstride) {
-    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+             uint32_t wstride, uint32_t blk0) {
+    uint32_t t = (blk0 + blockIdx.x) * 256u + threadIdx.x;
     if (t >= lv0.base[nblk]) return;
     const uint32_t g = map0[t];
     const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
@@ -1207,6 +1207,21 @@ int grow(void **p, size_t *cap, size_t need) {
     return BPG_OK;
 }
 
+int grow_pinned(void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return BPG_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 8 + 4096;
+    if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        return BPG_ENOMEM;
+    }
+    *cap = want;
+    return BPG_OK;
+}
+
 template <int C>
 static void launch_digits(hipStream_t s, const uint32_t *sc, int16_t *dg, size_t n, size_t total, const sc_map &sm,
                           uint32_t *zero, uint32_t nzero) {
@@ -1413,17 +1428,31 @@ static void msm_enqueue_sort(hipStream_t s, const msm_plan &pl, const msm_geom &
 static void msm_enqueue_accumulate(hipStream_t s, const msm_plan &pl, const msm_geom &g, const msm_bufs &b, const msm_layout &y,
                                    const seg_map &map, bool multi, uint32_t wstride, hipEvent_t ev_start = nullptr,
                                    hipEvent_t ev_stop = nullptr) {
-    const dim3 grid((unsigned)((g.cap_lv[0] + 255) / 256));
+    const unsigned blocks = (unsigned)((g.cap_lv[0] + 255) / 256);
     static const size_t acc_lds = [] {
         const char *e = getenv("BPG_ACC_LDS");
         return e ? (size_t)atoi(e) : (size_t)0;
     }();
-    if (multi)
-        hipExtLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), acc_lds, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
-                              y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
-    else
-        hipExtLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), acc_lds, s, ev_start, ev_stop, 0, b.entries, y.counts, y.ent_off,
-                              y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride);
+    // BPG_ACC_CHUNK=k: the pass goes out in launches of at most k blocks (experiment: streams share the hardware
+    // queues and a queue runs one kernel at a time, so a small kernel of another thread's round waits for a whole pass
+    // in front of it; measured, chunking changes nothing -- the queues idle between kernels, not inside them).  Off.
+    static const unsigned chunk = [] {
+        const char *e = getenv("BPG_ACC_CHUNK");
+        const int v = e ? atoi(e) : 0;
+        return (unsigned)(v > 0 ? v : 0x7fffffff);
+    }();
+    for (unsigned b0 = 0; b0 < blocks || b0 == 0; b0 += chunk) {
+        const unsigned nb = blocks - b0 < chunk ? blocks - b0 : chunk;
+        const dim3 grid(nb ? nb : 1);
+        hipEvent_t e0 = b0 == 0 ? ev_start : nullptr, e1 = b0 + nb >= blocks ? ev_stop : nullptr;
+        if (multi)
+            hipExtLaunchKernelGGL((k_accumulate<true>), grid, dim3(256), acc_lds, s, e0, e1, 0, b.entries, y.counts, y.ent_off,
+                                  y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride, (uint32_t)b0);
+        else
+            hipExtLaunchKernelGGL((k_accumulate<false>), grid, dim3(256), acc_lds, s, e0, e1, 0, b.entries, y.counts, y.ent_off,
+                                  y.L.lv[0], y.map0, b.partials + g.part_off[0], (uint32_t)g.nblk, pl.ls0, map, wstride, (uint32_t)b0);
+        if (!nb) break;
+    }
 }
 
 // merge passes and the bit-tree tail: leaves pl.outs points per bucket set in b.out
@@ -1756,8 +1785,12 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
                        map0, map1, (uint32_t)NE, S0, LS1);
     if (lane->acc_gate_job && lane->acc_gate_job != j) FOLD_CHECK_HIP(hipStreamWaitEvent(s, lane->acc_gate_job->ev[2], 0));
     FOLD_CHECK_HIP(hipEventRecord(j->ev[1], s));
-    hipLaunchKernelGGL((k_accumulate<true>), dim3((unsigned)((cap_lv[0] + 255) / 256)), dim3(256), 0, s, j->d_entries, counts, ent_off,
-                       L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, S0, map, (uint32_t)fb.wstride);
+    {
+        const unsigned blocks = (unsigned)((cap_lv[0] + 255) / 256), chunk = 0x7fffffff;
+        for (unsigned b0 = 0; b0 < blocks; b0 += chunk)
+            hipLaunchKernelGGL((k_accumulate<true>), dim3(blocks - b0 < chunk ? blocks - b0 : chunk), dim3(256), 0, s, j->d_entries, counts,
+                               ent_off, L.lv[0], map0, j->d_partials + part_off[0], (uint32_t)nblk, S0, map, (uint32_t)fb.wstride, (uint32_t)b0);
+    }
     FOLD_CHECK_HIP(hipEventRecord(j->ev[2], s));
     lane->acc_gate_job = j;
     for (int r = 1; r < nlevels; r++) {
@@ -1775,19 +1808,20 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
 
 int msm_fold_wait(bpg_msm_job *j) {
     if (!j || !j->busy) return BPG_EINVAL;
-    BPG_CHECK_HIP(hipEventSynchronize(j->ev[3]));
+    BPG_CHECK_HIP(wait_event(j->lane->ctx, j->ev[3]));
     j->busy.store(false, std::memory_order_release);
     return BPG_OK;
 }
 
 int msm_wait(bpg_msm_job *j, uint8_t *out, bool partial) {
     if (!j || !j->busy || !out) return BPG_EINVAL;
-    BPG_CHECK_HIP(hipEventSynchronize(j->ev[3]));
+    BPG_CHECK_HIP(wait_event(j->lane->ctx, j->ev[3]));
     float acc_ms = 0.f, tot_ms = 0.f;
     (void)hipEventElapsedTime(&acc_ms, j->ev[1], j->ev[2]);
     (void)hipEventElapsedTime(&tot_ms, j->ev[0], j->ev[3]);
     j->lane->last_acc_us = acc_ms * 1000.f;
     j->lane->last_total_us = tot_ms * 1000.f;
+    HostPhase hp_tail(HostPhase::TAIL_HOST);
     const msm_plan &pl = j->plan;
     for (int t = 0; t < pl.T; t++) {
         ge acc;

@@ -12,6 +12,7 @@
 //                                 ref: edwards_point.rs:45; scalar.rs:10-21; boolean.rs:20
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <string>
@@ -98,28 +99,27 @@ class TermVec {
     void append(const TermVec &o) {
         const uint32_t m = o.n_;                 // (o may be *this)
         reserve((size_t)n_ + m);
-        const Term *src = o.data();
-        Term *dst = data();
-        for (uint32_t i = 0; i < m; i++) dst[n_ + i] = src[i];
+        memmove(static_cast<void *>(data() + n_), o.data(), m * sizeof(Term));
         n_ += m;
     }
 
   private:
-    Term *data() { return heap_ ? heap_ : inl_; }
-    const Term *data() const { return heap_ ? heap_ : inl_; }
+    // raw storage: a Term is trivially copyable, and constructing six of them (zeroed coefficients) for every
+    // short-lived linear combination was a quarter of the capture time
+    Term *inl() { return reinterpret_cast<Term *>(inl_); }
+    const Term *inl() const { return reinterpret_cast<const Term *>(inl_); }
+    Term *data() { return heap_ ? heap_ : inl(); }
+    const Term *data() const { return heap_ ? heap_ : inl(); }
     void grow(size_t want) {
-        Term *nw = new Term[want];
-        const Term *old = data();
-        for (uint32_t i = 0; i < n_; i++) nw[i] = old[i];
-        delete[] heap_;
+        Term *nw = static_cast<Term *>(::operator new(want * sizeof(Term)));
+        memcpy(static_cast<void *>(nw), data(), n_ * sizeof(Term));
+        ::operator delete(heap_);
         heap_ = nw;
         cap_ = (uint32_t)want;
     }
     void assign(const TermVec &o) {
         reserve(o.n_);
-        const Term *src = o.data();
-        Term *dst = data();
-        for (uint32_t i = 0; i < o.n_; i++) dst[i] = src[i];
+        memcpy(static_cast<void *>(data()), o.data(), o.n_ * sizeof(Term));
         n_ = o.n_;
     }
     void steal(TermVec &o) {
@@ -131,21 +131,22 @@ class TermVec {
         } else {
             heap_ = nullptr;
             cap_ = INLINE;
-            for (uint32_t i = 0; i < o.n_; i++) inl_[i] = o.inl_[i];
+            memcpy(static_cast<void *>(inl_), o.inl_, o.n_ * sizeof(Term));
         }
         n_ = o.n_;
         o.n_ = 0;
     }
     void release() {
-        delete[] heap_;
+        ::operator delete(heap_);
         heap_ = nullptr;
         cap_ = INLINE;
         n_ = 0;
     }
-    Term inl_[INLINE];
+    alignas(8) unsigned char inl_[INLINE * (sizeof(Variable) + sizeof(sc))];
     Term *heap_ = nullptr;
     uint32_t n_ = 0, cap_ = INLINE;
 };
+static_assert(sizeof(Term) == sizeof(Variable) + sizeof(sc), "TermVec's inline storage is sized from the parts of a Term");
 
 struct LinearCombination {
     TermVec terms;
@@ -176,6 +177,15 @@ struct R1CSError : std::runtime_error {
 // them to the GPU flattening kernel without re-walking LC objects:
 //   term t: variable (kind, index), coefficient id (dictionary: circuits use a
 //   handful of distinct coefficients), constraint q = number of constrain() calls before it.
+// The structure of a captured circuit: which variable, which coefficient id and which constraint every
+// linear-combination term belongs to, in capture order.  Immutable once published; shared between the
+// circuit-structure cache (r1cs.hip: FlatCached) and the constraint systems that follow it.
+struct CircuitKey {
+    std::vector<uint32_t> term_var, term_coeff, term_q;
+    uint32_t num_constraints = 0, num_coeffs = 0;
+    uint32_t n_mult = 0;            // multipliers of the circuit (a hint: a follower reserves its witness vectors)
+};
+
 struct ConstraintStore {
     std::vector<uint32_t> term_var;      // kind << 28 | index   (index < 2^28)
     std::vector<uint32_t> term_coeff;    // index into coeffs
@@ -186,15 +196,40 @@ struct ConstraintStore {
     uint32_t id_one = 0xffffffffu, id_minus_one = 0xffffffffu;       // almost every coefficient is +1 or -1
     uint32_t intern(const sc &c);
     // n_mult / n_commit: multipliers allocated and values committed so far; a term outside them throws
-    // R1CSError(BPG_EINVAL) (a gadget built from another constraint system's variables)
-    void push(const LinearCombination &lc, size_t n_mult, size_t n_commit);
+    // R1CSError(BPG_EINVAL) (a gadget built from another constraint system's variables).  minus_var: one more
+    // term (minus_var, -1) after lc's (the implicit constraint of a multiply: lc - wire = 0).
+    void push(const LinearCombination &lc, size_t n_mult, size_t n_commit, const Variable *minus_var = nullptr);
+
+    // ---- following a cached circuit (capture of a circuit the library has seen before).
+    // The reference's callers capture one circuit over and over (every *_roundtrip_helper, ref:
+    // tests/edwards_point.rs:84-95; a prover service proves one statement shape).  While `follow_key` is set, the
+    // three term lists above stay empty and stand for the first `cur` terms of *follow_key: push() only COMPARES the
+    // incoming terms with the followed circuit's -- variable, constraint boundaries, and the coefficient VALUE
+    // against this store's own dictionary, exactly, no hashing -- and writes nothing.  At the first difference the
+    // prefix is copied out (materialize) and capture goes on as usual, so the result never depends on what was
+    // followed.  A circuit followed to its end is the cached circuit: prove / verify then take its resident
+    // flattening plan without hashing or comparing 12 bytes per term again.
+    std::shared_ptr<const CircuitKey> follow_key;
+    std::shared_ptr<void> follow_entry;          // the cache entry the key belongs to (r1cs.hip: FlatCached), if any
+    size_t cur = 0;
+    void follow(std::shared_ptr<const CircuitKey> key, std::shared_ptr<void> entry);   // only before anything is captured
+    void materialize();
+    bool followed_fully() const {
+        return follow_key && cur == follow_key->term_var.size() && num_constraints == follow_key->num_constraints &&
+               coeffs.size() == follow_key->num_coeffs;
+    }
+    size_t nterms() const { return follow_key ? cur : term_var.size(); }
+    std::shared_ptr<const CircuitKey> snapshot(size_t n_mult = 0) const;     // this store's structure as a key (copies)
+
+  private:
+    bool push_follow(const LinearCombination &lc, const Variable *minus_var);
 };
 
 class ConstraintSystem {
   public:
     virtual ~ConstraintSystem() {}
     struct Triple { Variable l, r, o; };
-    virtual Triple multiply(LinearCombination left, LinearCombination right) = 0;
+    virtual Triple multiply(const LinearCombination &left, const LinearCombination &right) = 0;
     // assignment may be null (verifier side / missing witness)
     virtual Triple allocate_multiplier(const Scalar *left, const Scalar *right) = 0;
     virtual void constrain(const LinearCombination &lc) = 0;
@@ -267,9 +302,19 @@ class Prover : public ConstraintSystem {
     Variable commit(const Scalar &v, const Scalar &v_blinding, uint8_t V32[32]);
     // batch form: one GPU launch for m commitments, transcript order preserved
     void commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, uint8_t *V32, Variable *vars);
-    Triple multiply(LinearCombination left, LinearCombination right) override;
+    Triple multiply(const LinearCombination &left, const LinearCombination &right) override;
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, a_L_.size(), v_.size()); }
+    // capture against a circuit seen before (ConstraintStore::follow); the constructor picks the prover-side circuit
+    // this process flattened last, tests name one
+    void follow(std::shared_ptr<const CircuitKey> key, std::shared_ptr<void> entry) {
+        if (key && key->n_mult > a_L_.capacity()) {          // the followed circuit's size: no regrowth of the witness vectors
+            a_L_.reserve(key->n_mult);
+            a_R_.reserve(key->n_mult);
+            a_O_.reserve(key->n_mult);
+        }
+        cs_.follow(std::move(key), std::move(entry));
+    }
     bool is_prover() const override { return true; }
     // (upstream's types make a registration from inside a callback impossible: the rcs handed to a callback is not
     // randomizable.  Here the handle is the same object, so the second phase refuses it instead of dropping it.)
@@ -299,8 +344,10 @@ class Prover : public ConstraintSystem {
     // prove() in three steps: transcript RNG set-up, blinding draws (the host's long Keccak chain), the rest
     int prove_begin(rng_fill_fn rng, void *rng_user);
     void draw_blindings();
+    void draw_blindings_into(uint8_t *pinned_slot);
     int prove_finish(R1CSProof &out);
     static int finish_group(Prover *const *ps, size_t g, R1CSProof *out);
+    static int finish_chunk(Prover *const *ps, size_t k, R1CSProof *out);
     // randomized constraints: first-phase commitments, the deferred callbacks, second-phase commitments
     int two_phase_prologue(R1CSProof &out);
     int commit3(size_t lo, size_t hi, const sc bl[3], const sc *sL, const sc *sR, uint8_t out96[96]);
@@ -321,6 +368,7 @@ class Prover : public ConstraintSystem {
     // bytes each, s_L then s_R -- and a kernel reduces them mod l (k_reduce512): on the host that reduction is about
     // half of the drawing time once eight Keccak states advance per permutation
     std::vector<uint8_t> s_raw_;
+    uint8_t *s_raw_pin_ = nullptr;        // the same 128 n bytes in the lane's pinned staging instead (not owned; valid from the draw to the upload)
     static constexpr size_t RAW_DRAW_MIN = 256;
     bool raw_draws() const { return deferred_.empty() && a_L_.size() >= RAW_DRAW_MIN; }
     double t_start_ = 0;
@@ -339,9 +387,10 @@ class Verifier : public ConstraintSystem {
   public:
     Verifier(const void *label, size_t label_len);
     Variable commit(const uint8_t V32[32]);
-    Triple multiply(LinearCombination left, LinearCombination right) override;
+    Triple multiply(const LinearCombination &left, const LinearCombination &right) override;
     Triple allocate_multiplier(const Scalar *left, const Scalar *right) override;
     void constrain(const LinearCombination &lc) override { cs_.push(lc, num_vars_, V_.size() / 32); }
+    void follow(std::shared_ptr<const CircuitKey> key, std::shared_ptr<void> entry) { cs_.follow(std::move(key), std::move(entry)); }
     bool is_prover() const override { return false; }
     void specify_randomized_constraints(RandomizedFn cb) override {
         if (phase2_) throw R1CSError(BPG_EINVAL, "specify_randomized_constraints inside a randomized-constraints callback");

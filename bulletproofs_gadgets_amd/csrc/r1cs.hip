@@ -116,6 +116,11 @@ __global__ void __launch_bounds__(256) k_dot_zpow(const uint32_t *__restrict__ t
     block_sum<1>(v, partial);
 }
 
+// Provers that share their launches (finish_group): every kernel boundary costs the whole chip a cache write-back, and
+// under dozens of prover threads the hardware queues spend more time between kernels than in them, so the lever on
+// proofs/s is launches per proof.  The blinding RNG still advances eight states per permutation (two draws per group).
+constexpr size_t GROUP_MAX = 16;
+
 // l(X), r(X) coefficient vectors and the per-block partial sums of t1..t6
 //   l1 = a_L + y^-i wR   l2 = a_O   l3 = s_L      r0 = wO - y^i   r1 = y^i a_R + wL   r3 = y^i s_R
 // (k_poly and k_eval, like the round kernels further down, take a group of up to 8 proofs: blockIdx.y = proof)
@@ -124,7 +129,7 @@ struct poly_proof {
     sc *l1, *r0, *r1, *r3, *partial;
 };
 struct poly_group {
-    poly_proof p[8];
+    poly_proof p[GROUP_MAX];
 };
 __global__ void __launch_bounds__(256) k_poly(uint32_t n, const poly_group G) {
     const poly_proof &P = G.p[blockIdx.y];
@@ -166,7 +171,7 @@ struct eval_proof {
     sc *a, *b, *sG, *sH;
 };
 struct eval_group {
-    eval_proof p[8];
+    eval_proof p[GROUP_MAX];
 };
 __global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, const eval_group G) {
     const eval_proof &P = G.p[blockIdx.y];
@@ -210,7 +215,7 @@ struct ipp_proof {
     sc w, u, uinv;             // Q = w B; the round's challenge and its inverse
 };
 struct ipp_group {
-    ipp_proof p[8];
+    ipp_proof p[GROUP_MAX];
 };
 __global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, const ipp_group G) {
     const ipp_proof &P = G.p[blockIdx.y];
@@ -318,6 +323,12 @@ __global__ void __launch_bounds__(256) k_verify_scalars(verify_args A, const sc 
     block_sum<1>(d, partial);
 }
 
+// the generator factors after the fold: sG = sH = 1 over the fm folded generators of each proof (blockIdx.y = 2 j + side)
+__global__ void __launch_bounds__(256) k_fill_ones(sc *__restrict__ s_all, uint32_t np, uint32_t fm) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < fm) st_sc(s_all + (size_t)blockIdx.y * np + i, sc_one());
+}
+
 // batch verification: acc[i] += rho * row[i]
 __global__ void __launch_bounds__(256) k_axpy(uint32_t n, sc rho, const sc *__restrict__ row, sc *__restrict__ acc) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -344,36 +355,41 @@ __global__ void __launch_bounds__(256) k_reduce512(const uint4 *__restrict__ raw
 // K3: fixed-base Pedersen commitments v B + r B~ with radix-16 comb tables, compressed on the device.
 // comb[(base*64 + w)*8 + (k-1)] = k * 16^w * base   (affine Niels).  16 lanes per commitment: lane l
 // adds the windows w = l mod 16 of both scalars (8 mixed additions), four butterfly steps sum the
-// lanes, lane 0 compresses.  (One lane per commitment walked 128 dependent additions: 0.64 ms for
-// any batch size.)
+// lanes.  (One lane per commitment walked 128 dependent additions: 0.64 ms for any batch size.)
+// The compression -- one inverse square root, ~290 dependent field operations, three quarters of
+// the kernel -- then runs with one lane per commitment in the block's first wave only: the sums go
+// through LDS, the other three waves retire.  (Round 2 compressed in lane 0 of every 16: every wave
+// of the launch stayed resident for the whole chain with 4 of 64 lanes working.)
 __global__ void __launch_bounds__(256) k_pedersen(const aniels_rec *__restrict__ comb, const sc *__restrict__ scalars /* [m][2] */,
                                                   uint32_t m, uint8_t *__restrict__ out32) {
+    __shared__ uint32_t sums[16][33];              // 16 commitments per block: X | Y | Z | T (row padded: no bank conflicts)
     const uint32_t lane_id = blockIdx.x * 256u + threadIdx.x;
     const uint32_t i = lane_id >> 4, sub = lane_id & 15u;
-    if (i >= m) return;                            // uniform over the 16 lanes of a commitment
     ge acc;
     ge_identity(acc);
-    for (int base = 0; base < 2; base++) {
-        sc s = ld_sc(scalars + 2 * (size_t)i + base);
-        // signed radix-16 digits without a serial carry: s + 0x88..8 (s < 2^253: no overflow), digit = nibble - 8
-        uint32_t c = 0;
+    if (i < m) {                                   // uniform over the 16 lanes of a commitment
+        for (int base = 0; base < 2; base++) {
+            sc s = ld_sc(scalars + 2 * (size_t)i + base);
+            // signed radix-16 digits without a serial carry: s + 0x88..8 (s < 2^253: no overflow), digit = nibble - 8
+            uint32_t c = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) s.v[k] = addc32(s.v[k], 0x88888888u, c, c);
+            for (int k = 0; k < 8; k++) s.v[k] = addc32(s.v[k], 0x88888888u, c, c);
 #pragma unroll
-        for (int jw = 0; jw < 4; jw++) {
-            const int w = (int)sub + 16 * jw;
-            const int d = (int)((s.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
-            if (d != 0) {
-                const int k = d < 0 ? -d : d;
-                const uint32_t *rec = comb[(size_t)(base * 64 + w) * 8 + (k - 1)].w;
-                ge_aniels q;
+            for (int jw = 0; jw < 4; jw++) {
+                const int w = (int)sub + 16 * jw;
+                const int d = (int)((s.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+                if (d != 0) {
+                    const int k = d < 0 ? -d : d;
+                    const uint32_t *rec = comb[(size_t)(base * 64 + w) * 8 + (k - 1)].w;
+                    ge_aniels q;
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    q.hYpX.v[t] = rec[t];
-                    q.hYmX.v[t] = rec[8 + t];
-                    q.Tdxy.v[t] = rec[16 + t];
+                    for (int t = 0; t < 8; t++) {
+                        q.hYpX.v[t] = rec[t];
+                        q.hYmX.v[t] = rec[8 + t];
+                        q.Tdxy.v[t] = rec[16 + t];
+                    }
+                    ge_madd(acc, acc, q, d < 0);
                 }
-                ge_madd(acc, acc, q, d < 0);
             }
         }
     }
@@ -383,10 +399,30 @@ __global__ void __launch_bounds__(256) k_pedersen(const aniels_rec *__restrict__
         ge_shfl_xor(other, acc, o, 16);
         ge_add(acc, acc, other);
     }
-    if (sub != 0) return;
+    if (sub == 0) {
+        uint32_t *row = sums[threadIdx.x >> 4];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            row[t] = acc.X.v[t];
+            row[8 + t] = acc.Y.v[t];
+            row[16 + t] = acc.Z.v[t];
+            row[24 + t] = acc.T.v[t];
+        }
+    }
+    __syncthreads();
+    const uint32_t ci = blockIdx.x * 16u + threadIdx.x;
+    if (threadIdx.x >= 16 || ci >= m) return;
+    const uint32_t *row = sums[threadIdx.x];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        acc.X.v[t] = row[t];
+        acc.Y.v[t] = row[8 + t];
+        acc.Z.v[t] = row[16 + t];
+        acc.T.v[t] = row[24 + t];
+    }
     uint32_t enc[8];
     ristretto_encode_w(enc, acc);
-    uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * (size_t)i);
+    uint4 *o = reinterpret_cast<uint4 *>(out32 + 32 * (size_t)ci);
     o[0] = make_uint4(enc[0], enc[1], enc[2], enc[3]);
     o[1] = make_uint4(enc[4], enc[5], enc[6], enc[7]);
 }
@@ -453,17 +489,101 @@ uint32_t ConstraintStore::intern(const sc &c) {
     return (uint32_t)coeffs.size() - 1;
 }
 
-void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_commit) {
+static const sc k_minus_one = (-Scalar(1)).v;
+
+void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_commit, const Variable *minus_var) {
     for (const auto &t : lc.terms) {
         const size_t lim = t.var.kind == VAR_COMMITTED ? n_commit : t.var.kind == VAR_ONE ? 1 : t.var.kind <= VAR_OUTPUT ? n_mult : 0;
         if (t.var.index >= lim) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
+    }
+    if (follow_key) {
+        if (push_follow(lc, minus_var)) {
+            num_constraints++;
+            return;
+        }
+        materialize();
     }
     for (const auto &t : lc.terms) {
         term_var.push_back(t.var.kind << 28 | t.var.index);
         term_coeff.push_back(intern(t.coeff.v));
         term_q.push_back(num_constraints);
     }
+    if (minus_var) {
+        term_var.push_back(minus_var->kind << 28 | minus_var->index);
+        term_coeff.push_back(intern(k_minus_one));
+        term_q.push_back(num_constraints);
+    }
     num_constraints++;
+}
+
+// One constraint against the followed circuit: same number of terms (the followed constraint neither ends earlier
+// nor goes on), same variables, same coefficient values.  The comparison is exact -- a coefficient id of the
+// followed circuit below this store's dictionary size names a value this store has seen and is compared with it; an
+// id AT the size says the followed circuit met a new value here, so the value must be new here too (intern() then
+// gives it exactly that id, as plain capture would).  Nothing is recorded: on a mismatch the caller copies the
+// prefix out and records this constraint itself, and a coefficient interned on the way is the one plain capture
+// would have interned at the same point.
+bool ConstraintStore::push_follow(const LinearCombination &lc, const Variable *minus_var) {
+    const CircuitKey &k = *follow_key;
+    const size_t nk = k.term_var.size(), len = lc.terms.size() + (minus_var ? 1 : 0), end = cur + len;
+    const uint32_t q = num_constraints;
+    if (end > nk) return false;
+    if (len && (k.term_q[cur] != q || k.term_q[end - 1] != q)) return false;
+    if (end < nk && k.term_q[end] == q) return false;
+    const uint32_t *kv = k.term_var.data() + cur, *kc = k.term_coeff.data() + cur;
+    size_t i = 0;
+    for (const auto &t : lc.terms) {
+        if (kv[i] != (t.var.kind << 28 | t.var.index)) return false;
+        const uint32_t id = kc[i];
+        if (id < coeffs.size()) {
+            if (!sc_eq(coeffs[id], t.coeff.v)) return false;
+        } else if (id != coeffs.size() || intern(t.coeff.v) != id) {
+            return false;
+        }
+        i++;
+    }
+    if (minus_var) {
+        if (kv[i] != (minus_var->kind << 28 | minus_var->index)) return false;
+        const uint32_t id = kc[i];
+        if (id != id_minus_one && (id != coeffs.size() || intern(k_minus_one) != id)) return false;
+    }
+    cur = end;
+    return true;
+}
+
+void ConstraintStore::follow(std::shared_ptr<const CircuitKey> key, std::shared_ptr<void> entry) {
+    if (!key || num_constraints || !term_var.empty() || !coeffs.empty()) return;      // only a store that has captured nothing
+    follow_key = std::move(key);
+    follow_entry = std::move(entry);
+    cur = 0;
+}
+
+void ConstraintStore::materialize() {
+    if (!follow_key) return;
+    const CircuitKey &k = *follow_key;
+    term_var.assign(k.term_var.begin(), k.term_var.begin() + cur);
+    term_coeff.assign(k.term_coeff.begin(), k.term_coeff.begin() + cur);
+    term_q.assign(k.term_q.begin(), k.term_q.begin() + cur);
+    follow_key.reset();
+    follow_entry.reset();
+    cur = 0;
+}
+
+std::shared_ptr<const CircuitKey> ConstraintStore::snapshot(size_t n_mult) const {
+    auto k = std::make_shared<CircuitKey>();
+    if (follow_key) {
+        k->term_var.assign(follow_key->term_var.begin(), follow_key->term_var.begin() + cur);
+        k->term_coeff.assign(follow_key->term_coeff.begin(), follow_key->term_coeff.begin() + cur);
+        k->term_q.assign(follow_key->term_q.begin(), follow_key->term_q.begin() + cur);
+    } else {
+        k->term_var = term_var;
+        k->term_coeff = term_coeff;
+        k->term_q = term_q;
+    }
+    k->num_constraints = num_constraints;
+    k->num_coeffs = (uint32_t)coeffs.size();
+    k->n_mult = (uint32_t)n_mult;
+    return k;
 }
 
 Scalar sonny_a() { return -Scalar(1); }
@@ -628,7 +748,8 @@ struct FlatCached {
     uint32_t n = 0, m = 0;
     bool want_wc = false;
     uint64_t hash = 0;
-    std::vector<uint32_t> term_var, term_coeff, term_q;     // the key
+    uint64_t ctx_id = 0;                                    // the context whose device holds the arrays below
+    std::shared_ptr<const CircuitKey> key;                  // the captured term lists (also what later captures follow)
     FlatPlan fp;                                            // sizes only (the vectors live in HBM)
     uint32_t *d_off = nullptr, *d_tc = nullptr, *d_tq = nullptr, *d_oc = nullptr, *d_oq = nullptr;
     void *d_block = nullptr;
@@ -663,8 +784,38 @@ static uint64_t hash_words(const std::vector<uint32_t> &v, uint64_t h) {
     return r;
 }
 
-static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc,
+// The circuit each side flattened last in this process: what the next Prover (role 0) / Verifier (role 1) follows
+// while it captures (ConstraintStore::follow).  A wrong guess costs one early mismatch.
+static std::mutex g_last_mu;
+static std::shared_ptr<FlatCached> g_last_shape[2];
+
+static void remember_shape(const std::shared_ptr<FlatCached> &e) {
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    g_last_shape[e->want_wc ? 1 : 0] = e;
+}
+static std::shared_ptr<FlatCached> last_shape(int role) {
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    return g_last_shape[role];
+}
+void forget_shapes_of(uint64_t ctx_id) {                    // bpg_shutdown: the entries' device memory goes with the context
+    std::lock_guard<std::mutex> lk(g_last_mu);
+    for (auto &e : g_last_shape)
+        if (e && e->ctx_id == ctx_id) e.reset();
+}
+
+static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc,
                             std::shared_ptr<FlatCached> &out) {
+    // a capture that followed a cached circuit to its end IS that circuit (every term was compared on the way)
+    if (cs.followed_fully() && cs.follow_entry) {
+        auto e = std::static_pointer_cast<FlatCached>(cs.follow_entry);
+        if (e->ctx_id == ctx->id && e->n == n && e->m == m && e->want_wc == want_wc) {
+            ctx->flat_hits++;
+            ctx->flat_followed++;
+            out = e;
+            return BPG_OK;
+        }
+    }
+    cs.materialize();
     uint64_t h = 0x243F6A8885A308D3ull ^ ((uint64_t)n << 32) ^ m ^ (want_wc ? 1ull << 63 : 0);
     h = hash_words(cs.term_var, h);
     h = hash_words(cs.term_coeff, h);
@@ -676,12 +827,15 @@ static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore 
     }
     for (auto &c : candidates) {
         auto e = std::static_pointer_cast<FlatCached>(c);
-        if (e->hash == h && e->n == n && e->m == m && e->want_wc == want_wc && e->term_var == cs.term_var &&
-            e->term_coeff == cs.term_coeff && e->term_q == cs.term_q) {
-            std::lock_guard<std::mutex> lk(ctx->flat_mu);                  // most recently used last
-            auto it = std::find(ctx->flat_cache.begin(), ctx->flat_cache.end(), c);
-            if (it != ctx->flat_cache.end()) std::rotate(it, it + 1, ctx->flat_cache.end());
+        if (e->hash == h && e->n == n && e->m == m && e->want_wc == want_wc && e->key->num_constraints == cs.num_constraints &&
+            e->key->term_var == cs.term_var && e->key->term_coeff == cs.term_coeff && e->key->term_q == cs.term_q) {
+            {
+                std::lock_guard<std::mutex> lk(ctx->flat_mu);              // most recently used last
+                auto it = std::find(ctx->flat_cache.begin(), ctx->flat_cache.end(), c);
+                if (it != ctx->flat_cache.end()) std::rotate(it, it + 1, ctx->flat_cache.end());
+            }
             ctx->flat_hits++;
+            remember_shape(e);
             out = e;
             return BPG_OK;
         }
@@ -691,9 +845,8 @@ static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore 
     e->m = m;
     e->want_wc = want_wc;
     e->hash = h;
-    e->term_var = cs.term_var;
-    e->term_coeff = cs.term_coeff;
-    e->term_q = cs.term_q;
+    e->ctx_id = ctx->id;
+    e->key = cs.snapshot(n);
     build_flat_plan(cs, n, m, want_wc, e->fp);
     FlatPlan &fp = e->fp;
     const size_t w_off = fp.nslots + 1, w_t = fp.nterms + 1, w_o = fp.nones + 1;
@@ -715,7 +868,7 @@ static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore 
         BPG_CHECK_HIP(hipMemcpyAsync(e->d_oc, fp.one_coeff.data(), fp.nones * 4, hipMemcpyHostToDevice, s));
         BPG_CHECK_HIP(hipMemcpyAsync(e->d_oq, fp.one_q.data(), fp.nones * 4, hipMemcpyHostToDevice, s));
     }
-    BPG_CHECK_HIP(hipStreamSynchronize(s));                 // complete before any other thread's stream can read it
+    BPG_CHECK_HIP(lane_sync(lane));                 // complete before any other thread's stream can read it
     for (auto *v : {&fp.slot_off, &fp.t_coeff, &fp.t_q, &fp.one_coeff, &fp.one_q}) std::vector<uint32_t>().swap(*v);
     {
         std::lock_guard<std::mutex> lk(ctx->flat_mu);
@@ -723,6 +876,7 @@ static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, const ConstraintStore 
         ctx->flat_cache.push_back(e);
         ctx->flat_misses++;
     }
+    remember_shape(e);
     out = e;
     return BPG_OK;
 }
@@ -827,7 +981,7 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, 
     BPG_CHECK_HIP(device_malloc(&g->d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
     hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), (aniels_rec *)g->d_comb);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipStreamSynchronize(lane->stream));
+    BPG_CHECK_HIP(lane_sync(lane));
     guard.g = nullptr;
     *out = g;
     return BPG_OK;
@@ -858,7 +1012,7 @@ static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
     BPG_CHECK_HIP(hipGetLastError());
     BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     return BPG_OK;
 }
 
@@ -904,12 +1058,17 @@ static int finish_partials(Gens *g, const uint8_t *mine, int T, uint8_t *out32) 
 // One fixed-base MSM with T targets over this rank's part of the generator table.  Rows of
 // `stride` scalars each; segment k reads its scalars at segs[k].sc_off.
 static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, size_t stride, int T, uint8_t *out32,
-                    float density = 1.f) {
+                    float density = 1.f, HostPhase::Id ph_submit = HostPhase::AS_SUBMIT, HostPhase::Id ph_wait = HostPhase::AS_WAIT) {
     size_t n = 0;
     for (int k = 0; k < nseg; k++) n += segs[k].len;
     bpg_msm_job *job = nullptr;
-    int rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints(), density}, stride);
+    int rc;
+    {
+        HostPhase hp(ph_submit);
+        rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints(), density}, stride);
+    }
     if (rc) return rc;
+    HostPhase hp(ph_wait);
     if (g->world == 1) return msm_wait(job, out32, false);
     std::vector<uint8_t> mine((size_t)T * 128);
     if ((rc = msm_wait(job, mine.data(), true))) return rc;
@@ -918,7 +1077,10 @@ static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, si
 
 // =================================================================== Prover
 
-Prover::Prover(Gens *gens, const void *label, size_t label_len) : gens_(gens), tr_(label, label_len) { tr_.r1cs_domain_sep(); }
+Prover::Prover(Gens *gens, const void *label, size_t label_len) : gens_(gens), tr_(label, label_len) {
+    tr_.r1cs_domain_sep();
+    if (auto e = last_shape(0)) follow(e->key, e);
+}
 
 Variable Prover::commit(const Scalar &v, const Scalar &v_blinding, uint8_t V32[32]) {
     Variable var;
@@ -932,6 +1094,7 @@ void Prover::commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, u
         vr[2 * i] = v[i].v;
         vr[2 * i + 1] = v_blinding[i].v;
     }
+    HostPhase hp(HostPhase::CAPTURE_COMMIT);
     int rc = pedersen_batch(gens_, vr.data(), m, V32);
     if (rc) throw R1CSError(rc, "pedersen commitment kernel failed");
     for (size_t i = 0; i < m; i++) {
@@ -966,17 +1129,15 @@ Scalar Prover::eval(const LinearCombination &lc) const {
     return acc;
 }
 
-ConstraintSystem::Triple Prover::multiply(LinearCombination left, LinearCombination right) {
+ConstraintSystem::Triple Prover::multiply(const LinearCombination &left, const LinearCombination &right) {
     Scalar l = eval(left), r = eval(right), o = l * r;
     uint32_t i = (uint32_t)a_L_.size();
     Triple t{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
     a_L_.push_back(l.v);
     a_R_.push_back(r.v);
     a_O_.push_back(o.v);
-    left.terms.push_back({t.l, -Scalar(1)});
-    right.terms.push_back({t.r, -Scalar(1)});
-    cs_.push(left, a_L_.size(), v_.size());
-    cs_.push(right, a_L_.size(), v_.size());
+    cs_.push(left, a_L_.size(), v_.size(), &t.l);          // left - a_L[i] = 0
+    cs_.push(right, a_L_.size(), v_.size(), &t.r);         // right - a_R[i] = 0
     return t;
 }
 
@@ -1026,7 +1187,7 @@ int Prover::commit3(size_t lo, size_t hi, const sc bl[3], const sc *sL, const sc
         BPG_CHECK_HIP(hipMemcpyAsync(rows + 2 * N1 + 1, sL, k * 32, hipMemcpyHostToDevice, s));
         BPG_CHECK_HIP(hipMemcpyAsync(rows + 2 * N1 + 1 + k, sR, k * 32, hipMemcpyHostToDevice, s));
     }
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     msm_seg segs[3] = {pedersen_seg(gens_, 1, 1, 0), gen_seg(gens_, 0, lo, hi, 1), gen_seg(gens_, 1, lo, hi, 1 + k)};
     return gens_msm(gens_, segs, 3, rows, N1, 3, out96);
 }
@@ -1102,7 +1263,9 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
 
 // ---- transcript RNG (host, sequential Keccak)
 int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
+    HostPhase hp(HostPhase::RNG_BEGIN);
     t_start_ = now_ms();
+    s_raw_pin_ = nullptr;
     const size_t n = a_L_.size(), m = v_.size();
     if (consumed_) {
         set_last_error_msg("prove: this prover's randomized-constraint callbacks have already run (a prover proves once)");
@@ -1122,15 +1285,29 @@ int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
     return BPG_OK;
 }
 
+// a prover alone: its raw draws take the whole of the lane's pinned staging
 void Prover::draw_blindings() {
+    uint8_t *slot = nullptr;
+    if (raw_draws() && gens_)
+        if (bpg_lane *lane = lane_of(gens_->ctx))
+            if (grow_pinned(&lane->h_raw, &lane->h_raw_cap, 128 * a_L_.size()) == BPG_OK) slot = (uint8_t *)lane->h_raw;
+    draw_blindings_into(slot);
+}
+
+// pinned_slot: where the raw draws (128 n bytes) go in the lane's pinned staging; null: pageable memory of the prover's own
+void Prover::draw_blindings_into(uint8_t *pinned_slot) {
     const double t0 = now_ms();
     const size_t n = a_L_.size();
     i_bl_ = rng_->scalar();
     o_bl_ = rng_->scalar();
     s_bl_ = rng_->scalar();
     if (raw_draws()) {
-        s_raw_.resize(128 * n);
-        for (size_t i = 0; i < 2 * n; i++) rng_->fill_bytes(&s_raw_[64 * i], 64);        // s_L[0..n) then s_R[0..n)
+        uint8_t *dst = s_raw_pin_ = pinned_slot;
+        if (!dst) {
+            s_raw_.resize(128 * n);
+            dst = s_raw_.data();
+        }
+        for (size_t i = 0; i < 2 * n; i++) rng_->fill_bytes(dst + 64 * i, 64);           // s_L[0..n) then s_R[0..n)
     } else {
         s_L_.resize(n);
         s_R_.resize(n);
@@ -1145,57 +1322,103 @@ int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rn
         int rc = ps[j]->prove_begin(rng_fn, rng_user);
         if (rc) return rc;
     }
-    for (size_t j0 = 0; j0 < k; j0 += 8) {
-        const size_t g = k - j0 < 8 ? k - j0 : 8;
-        const size_t n = ps[j0]->a_L_.size();
-        bool same = g > 1;
-        for (size_t l = 1; l < g; l++) same = same && ps[j0 + l]->a_L_.size() == n;
-        for (size_t l = 0; l < g; l++) same = same && ps[j0 + l]->deferred_.empty();
-        TranscriptRng *r[8];
-        for (size_t l = 0; l < 8; l++) r[l] = ps[j0 + (l < g ? l : 0)]->rng_.get();     // spare lanes repeat lane 0
-        TranscriptRngLanes8 lanes;
-        if (!same || !lanes.load(r)) {                      // different circuits: every prover on its own
-            for (size_t l = 0; l < g; l++) ps[j0 + l]->draw_blindings();
-            continue;
+    // chunks of GROUP_MAX provers: blindings drawn eight provers at a time (TranscriptRngLanes8), then one GPU pass for
+    // the chunk.  (prove_begin has asked the external RNG for every prover already, in order: the bytes do not depend
+    // on how the provers are chunked.)
+    for (size_t c0 = 0; c0 < k; c0 += GROUP_MAX) {
+        const size_t G = k - c0 < GROUP_MAX ? k - c0 : GROUP_MAX;
+        bool done[GROUP_MAX] = {};
+        // the chunk's raw draws go straight into the lane's pinned staging when its provers share a context and size
+        const size_t n0 = ps[c0]->a_L_.size();
+        bool one_ctx = ps[c0]->gens_ != nullptr && ps[c0]->raw_draws();
+        for (size_t l = 1; l < G && one_ctx; l++)
+            one_ctx = ps[c0 + l]->gens_ && ps[c0 + l]->gens_->ctx == ps[c0]->gens_->ctx && ps[c0 + l]->a_L_.size() == n0 && ps[c0 + l]->raw_draws();
+        bpg_lane *lane = one_ctx ? lane_of(ps[c0]->gens_->ctx) : nullptr;
+        const bool pinned = lane && grow_pinned(&lane->h_raw, &lane->h_raw_cap, G * 128 * n0) == BPG_OK;
+        for (size_t j0 = c0; j0 < c0 + G; j0 += 8) {
+            const size_t g = c0 + G - j0 < 8 ? c0 + G - j0 : 8;
+            const size_t n = ps[j0]->a_L_.size();
+            bool same = g > 1;
+            for (size_t l = 1; l < g; l++) same = same && ps[j0 + l]->a_L_.size() == n;
+            for (size_t l = 0; l < g; l++) same = same && ps[j0 + l]->deferred_.empty();
+            TranscriptRng *r[8];
+            for (size_t l = 0; l < 8; l++) r[l] = ps[j0 + (l < g ? l : 0)]->rng_.get();     // spare lanes repeat lane 0
+            TranscriptRngLanes8 lanes;
+            if (!same || !lanes.load(r)) {                      // different circuits: every prover on its own, start to finish
+                for (size_t l = 0; l < g; l++) {                //   (one prover's raw draws fill the lane's pinned staging at a time:
+                    if (pinned) continue;                       //    not while the chunk's other draws sit there)
+                    ps[j0 + l]->draw_blindings();
+                    if (int rc = finish_group(ps + j0 + l, 1, out + j0 + l)) return rc;
+                    done[j0 + l - c0] = true;
+                }
+                if (!pinned) continue;
+                for (size_t l = 0; l < g; l++)                  // pinned chunk whose lanes would not load (or a lone last prover):
+                    ps[j0 + l]->draw_blindings_into((uint8_t *)lane->h_raw + (j0 + l - c0) * 128 * n);     // one by one, into its slot
+                continue;
+            }
+            HostPhase hp(HostPhase::RNG_DRAW);
+            const double t0 = now_ms();
+            sc d[8];
+            lanes.scalars(d);
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->i_bl_ = d[l];
+            lanes.scalars(d);
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->o_bl_ = d[l];
+            lanes.scalars(d);
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_bl_ = d[l];
+            if (ps[j0]->raw_draws()) {
+                uint8_t buf[8][64], *dst[8];
+                for (size_t l = 0; l < g; l++) {
+                    Prover &p = *ps[j0 + l];
+                    if (pinned) {
+                        dst[l] = p.s_raw_pin_ = (uint8_t *)lane->h_raw + (j0 + l - c0) * 128 * n;
+                    } else {
+                        p.s_raw_.resize(128 * n);
+                        dst[l] = p.s_raw_.data();
+                    }
+                }
+                for (size_t i = 0; i < 2 * n; i++) {
+                    lanes.fill64(buf);
+                    for (size_t l = 0; l < g; l++) memcpy(dst[l] + 64 * i, buf[l], 64);
+                }
+            } else {
+                for (size_t l = 0; l < g; l++) {
+                    ps[j0 + l]->s_L_.resize(n);
+                    ps[j0 + l]->s_R_.resize(n);
+                }
+                for (size_t i = 0; i < n; i++) {
+                    lanes.scalars(d);
+                    for (size_t l = 0; l < g; l++) ps[j0 + l]->s_L_[i] = d[l];
+                }
+                for (size_t i = 0; i < n; i++) {
+                    lanes.scalars(d);
+                    for (size_t l = 0; l < g; l++) ps[j0 + l]->s_R_[i] = d[l];
+                }
+            }
+            lanes.store(r, (int)g);
+            const double per = (now_ms() - t0) / (double)g;
+            for (size_t l = 0; l < g; l++) ps[j0 + l]->timing.rng_ms = per;
         }
-        const double t0 = now_ms();
-        sc d[8];
-        lanes.scalars(d);
-        for (size_t l = 0; l < g; l++) ps[j0 + l]->i_bl_ = d[l];
-        lanes.scalars(d);
-        for (size_t l = 0; l < g; l++) ps[j0 + l]->o_bl_ = d[l];
-        lanes.scalars(d);
-        for (size_t l = 0; l < g; l++) ps[j0 + l]->s_bl_ = d[l];
-        if (ps[j0]->raw_draws()) {
-            uint8_t buf[8][64];
-            for (size_t l = 0; l < g; l++) ps[j0 + l]->s_raw_.resize(128 * n);
-            for (size_t i = 0; i < 2 * n; i++) {
-                lanes.fill64(buf);
-                for (size_t l = 0; l < g; l++) memcpy(&ps[j0 + l]->s_raw_[64 * i], buf[l], 64);
+        // the GPU part, over the runs of provers that are not finished yet
+        for (size_t a = 0; a < G;) {
+            if (done[a]) {
+                a++;
+                continue;
             }
-        } else {
-            for (size_t l = 0; l < g; l++) {
-                ps[j0 + l]->s_L_.resize(n);
-                ps[j0 + l]->s_R_.resize(n);
-            }
-            for (size_t i = 0; i < n; i++) {
-                lanes.scalars(d);
-                for (size_t l = 0; l < g; l++) ps[j0 + l]->s_L_[i] = d[l];
-            }
-            for (size_t i = 0; i < n; i++) {
-                lanes.scalars(d);
-                for (size_t l = 0; l < g; l++) ps[j0 + l]->s_R_[i] = d[l];
-            }
+            size_t b = a;
+            while (b < G && !done[b]) b++;
+            if (int rc = finish_chunk(ps + c0 + a, b - a, out + c0 + a)) return rc;
+            a = b;
         }
-        lanes.store(r, (int)g);
-        const double per = (now_ms() - t0) / (double)g;
-        for (size_t l = 0; l < g; l++) ps[j0 + l]->timing.rng_ms = per;
     }
-    // the GPU part: consecutive provers of one size and generator object share their MSM launches
-    const size_t gmax = 8;
+    return BPG_OK;
+}
+
+// the GPU part of one chunk of up to GROUP_MAX provers whose blindings are drawn (the chunk's raw draws sit in the lane's
+// pinned staging until then): consecutive provers of one size and generator object share their MSM launches
+int Prover::finish_chunk(Prover *const *ps, size_t k, R1CSProof *out) {
     for (size_t j0 = 0; j0 < k;) {
         size_t g = 1;
-        while (j0 + g < k && g < gmax && ps[j0 + g]->a_L_.size() == ps[j0]->a_L_.size() && ps[j0 + g]->gens_ == ps[j0]->gens_ &&
+        while (j0 + g < k && ps[j0 + g]->a_L_.size() == ps[j0]->a_L_.size() && ps[j0 + g]->gens_ == ps[j0]->gens_ &&
                ps[j0]->deferred_.empty() && ps[j0 + g]->deferred_.empty())       // randomized constraints: one prover at a time
             g++;
         int rc = finish_group(ps + j0, g, out + j0);
@@ -1269,9 +1492,16 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg) : ctx->tune.ipp_fold;
     if (gens->world != 1 || k0 < 1 || (size_t)k0 >= lg || (np >> k0) < 32) k0 = 0;
     const size_t fm = k0 ? np >> k0 : 0;                  // folded generators per side
+    // The rounds after the fold run FIXED-BASE as well: the folded generators get their own table of 2^(c w) multiples
+    // (one doubling chain per point, built once per group).  A variable-base MSM leaves ~250 doublings per target to
+    // the host's window combination -- 16 targets x 11 rounds of them were more than half of a group's inner-product
+    // latency and 2.8 ms of host CPU per proof; fixed-base leaves c - 1.
+    const size_t fpts = g * 2 * fm + 1;                   // [tab_0 | .. | tab_{g-1} | B]
+    const bool fold_fb = k0 && fpts <= ((size_t)1 << 17);
+    const int fold_c = 9, fold_W = fold_fb ? fixed_base_windows(fold_c) : 1;
     // MSM scalar rows: 2g rows of NR before the fold, of g * 2 fm + 1 after it
     const size_t row_words = std::max(g * 2 * NR, 2 * g * (g * 2 * fm + 1));
-    size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256(g * 2 * fm * 128) + (1 << 16) +
+    size_t need = pad256(g * 3 * N1 * 32) + pad256(row_words * 32) + pad256(g * 2 * np * 32) + pad256((size_t)fold_W * fpts * 128) + (1 << 16) +
                   g * pad256(128 * n + 64);
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
@@ -1284,13 +1514,16 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     Arena ar(lane);
     int rc = ar.reserve(need);
     if (rc) return rc;
+    std::unique_ptr<HostPhase> hp_up(new HostPhase(HostPhase::UPLOAD));
     sc *d_rows_all = ar.take<sc>(g * 3 * N1);             // proof j: rows 3j .. 3j+2
     sc *d_rowLR_all = ar.take<sc>(row_words);             // proof j: rows 2j, 2j+1
     sc *d_s_all = ar.take<sc>(g * 2 * np);                // proof j: [sG (np) | sH (np)]
-    aniels_rec *d_tab_all = (aniels_rec *)ar.take<uint8_t>(g * 2 * fm * 128 + 128);   // proof j: [G' (fm) | H' (fm)]
+    aniels_rec *d_tab_all = (aniels_rec *)ar.take<uint8_t>((size_t)fold_W * fpts * 128);   // proof j: [G' (fm) | H' (fm)]; then B; then the shifted blocks
     BPG_CHECK_HIP(hipMemsetAsync(d_rows_all, 0, g * 3 * N1 * 32, s));
     std::vector<std::vector<sc>> keep_sL(g), keep_sR(g);  // pageable sources of async copies: alive until the sync
     std::vector<std::vector<uint8_t>> keep_raw(g);
+    // the witness vectors go through the lane's pinned staging too (one host copy, then DMA)
+    uint8_t *h_wit = n && grow_pinned(&lane->h_wit, &lane->h_wit_cap, g * 3 * n * 32) == BPG_OK ? (uint8_t *)lane->h_wit : nullptr;
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         PF &f = pf[j];
@@ -1311,13 +1544,25 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + N1, &p.o_bl_, 32, hipMemcpyHostToDevice, s));
         BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + 2 * N1, &p.s_bl_, 32, hipMemcpyHostToDevice, s));
         if (n) {
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, p.a_L_.data(), n * 32, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, p.a_R_.data(), n * 32, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, p.a_O_.data(), n * 32, hipMemcpyHostToDevice, s));
-            if (!keep_raw[j].empty()) {              // raw draws: reduced mod l on the device, straight into row 2
-                if (keep_raw[j].size() != 128 * n) return BPG_EINVAL;
+            const sc *hL = p.a_L_.data(), *hR = p.a_R_.data(), *hO = p.a_O_.data();
+            if (h_wit) {
+                sc *w = (sc *)(h_wit + j * 3 * n * 32);
+                memcpy(w, hL, n * 32);
+                memcpy(w + n, hR, n * 32);
+                memcpy(w + 2 * n, hO, n * 32);
+                hL = w;
+                hR = w + n;
+                hO = w + 2 * n;
+            }
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, hL, (h_wit ? 2 : 1) * n * 32, hipMemcpyHostToDevice, s));   // staged: a_L | a_R are adjacent on both sides
+            if (!h_wit) BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
+            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, hO, n * 32, hipMemcpyHostToDevice, s));
+            const uint8_t *raw = p.s_raw_pin_ ? p.s_raw_pin_ : keep_raw[j].empty() ? nullptr : keep_raw[j].data();
+            if (raw) {                               // raw draws: reduced mod l on the device, straight into row 2
+                if (!p.s_raw_pin_ && keep_raw[j].size() != 128 * n) return BPG_EINVAL;
+                p.s_raw_pin_ = nullptr;
                 uint4 *d_raw = (uint4 *)ar.take<uint8_t>(128 * n);
-                BPG_CHECK_HIP(hipMemcpyAsync(d_raw, keep_raw[j].data(), 128 * n, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(hipMemcpyAsync(d_raw, raw, 128 * n, hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_reduce512, dim3(grid256(2 * n)), dim3(256), 0, s, d_raw, f.d_sL, (uint32_t)(2 * n));
             } else {
                 if (keep_sL[j].size() != n || keep_sR[j].size() != n) return BPG_EINVAL;
@@ -1326,10 +1571,11 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             }
         }
     }
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     keep_sL.clear();
     keep_sR.clear();
     keep_raw.clear();
+    hp_up.reset();
 
     // ---- A_I1, A_O1, S1 of every proof: one 3g-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
@@ -1347,6 +1593,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
     // ---- challenges y, z; flatten, l/r polynomials, t coefficients
     const double t2 = now_ms();
+    std::unique_ptr<HostPhase> hp_poly(new HostPhase(HostPhase::FLATTEN_POLY));
     poly_group pgrp{};
     eval_group egrp{};
     for (size_t j = 0; j < g; j++) {
@@ -1397,10 +1644,12 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         if (n) BPG_CHECK_HIP(hipMemcpyAsync(f.h_part.data(), f.d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
         if (m) BPG_CHECK_HIP(hipMemcpyAsync(f.wV.data(), f.d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
     }
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
 
+    hp_poly.reset();
     // ---- T_1, T_3..T_6 of every proof: one batch of 5g Pedersen commitments
     {
+        HostPhase hp_t(HostPhase::T_COMMIT);
         std::vector<sc> vr(10 * g);
         std::vector<uint8_t> Ts(160 * g);
         for (size_t j = 0; j < g; j++) {
@@ -1471,29 +1720,30 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     // the fm folded ones of each proof; the group's tables form one point set [tab_0 | .. | tab_{g-1} | B] and
     // proof j's two rows are zero outside its own block, so one variable-base MSM still serves the group.
     size_t cnp = np, cstride = NR, cblk = nblk_np;
-    std::vector<sc> ones;
     ipp_group grp{};
     for (size_t k = 0; k < lg; k++, nk >>= 1) {
         if (k0 && k == (size_t)k0) {
-            BPG_CHECK_HIP(hipStreamSynchronize(s));         // the folds of round k-1 wrote sG / sH
+            HostPhase hp_f(HostPhase::FOLD);
+            BPG_CHECK_HIP(lane_sync(lane));         // the folds of round k-1 wrote sG / sH
             msm_seg fs[2] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np)};
             bpg_msm_job *job = nullptr;
             if ((rc = msm_fold_submit(ctx, fs, d_s_all, 2 * np, (int)g, np, fm, msm_fixed_base{gens->fb_c, gens->npoints(), 1.f},
                                       d_tab_all, &job)))
                 return rc;
             if ((rc = msm_fold_wait(job))) return rc;
+            if (fold_fb) {
+                BPG_CHECK_HIP(hipMemcpyAsync(d_tab_all + g * 2 * fm, gens->table->d_table + gens->off_B(), sizeof(aniels_rec),
+                                             hipMemcpyDeviceToDevice, s));
+                if ((rc = table_build_shifted(ctx, d_tab_all, fpts, fold_c, fold_W))) return rc;
+            }
             cnp = fm;
             cstride = g * 2 * fm + 1;
             cblk = grid256(fm);
-            ones.assign(fm, sc_one());
             BPG_CHECK_HIP(hipMemsetAsync(d_rowLR_all, 0, 2 * g * cstride * 32, s));
-            for (size_t j = 0; j < g; j++) {
-                PF &f = pf[j];
-                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sG, ones.data(), fm * 32, hipMemcpyHostToDevice, s));
-                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sH, ones.data(), fm * 32, hipMemcpyHostToDevice, s));
-                f.d_rowLR = d_rowLR_all + 2 * j * cstride + j * 2 * fm;
-            }
+            hipLaunchKernelGGL(k_fill_ones, dim3(grid256(fm), (unsigned)(2 * g)), dim3(256), 0, s, d_s_all, (uint32_t)np, (uint32_t)fm);
+            for (size_t j = 0; j < g; j++) pf[j].d_rowLR = d_rowLR_all + 2 * j * cstride + j * 2 * fm;
         }
+        std::unique_ptr<HostPhase> hp_rows(new HostPhase(HostPhase::IPP_ROWS));
         const size_t boff = cnp == np ? 2 * np : cstride - 1;        // where a row keeps the scalar of B
         for (size_t j = 0; j < g; j++) {
             PF &f = pf[j];
@@ -1508,18 +1758,30 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, grp);
         hipLaunchKernelGGL(k_ipp_c, dim3(1, (unsigned)g), dim3(256), 0, s, (uint32_t)cblk, grp);
         BPG_CHECK_HIP(hipGetLastError());
-        BPG_CHECK_HIP(hipStreamSynchronize(s));
+        BPG_CHECK_HIP(lane_sync(lane));
+        hp_rows.reset();
         if (cnp == np) {
             msm_seg segs[3] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np), pedersen_seg(gens, 0, 1, 2 * np)};
-            if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f))) return rc;     // half of every row is zero
+            if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f, HostPhase::IPP_SUBMIT, HostPhase::IPP_WAIT)))
+                return rc;     // half of every row is zero
         } else {
             msm_seg segs[2] = {msm_seg{d_tab_all, g * 2 * fm, 0}, pedersen_seg(gens, 0, 1, g * 2 * fm)};
             bpg_msm_job *job = nullptr;
-            if ((rc = msm_submit(ctx, segs, 2, d_rowLR_all, cstride, (int)(2 * g), false, &job,
-                                 msm_fixed_base{0, 0, 1.f / (float)(2 * g)}, 0)))
-                return rc;
+            {
+                HostPhase hp_s(HostPhase::IPP_SUBMIT);
+                if (fold_fb) {
+                    msm_seg one{d_tab_all, fpts, 0};              // B sits behind the tables, where the rows keep its scalar
+                    rc = msm_submit(ctx, &one, 1, d_rowLR_all, cstride, (int)(2 * g), false, &job,
+                                    msm_fixed_base{fold_c, fpts, 1.f / (float)(2 * g)}, 0);
+                } else {
+                    rc = msm_submit(ctx, segs, 2, d_rowLR_all, cstride, (int)(2 * g), false, &job, msm_fixed_base{0, 0, 1.f / (float)(2 * g)}, 0);
+                }
+            }
+            if (rc) return rc;
+            HostPhase hp_w(HostPhase::IPP_WAIT);
             if ((rc = msm_wait(job, lr.data(), false))) return rc;
         }
+        HostPhase hp_h(HostPhase::IPP_HOST);
         for (size_t j = 0; j < g; j++) {
             Prover &p = *ps[j];
             R1CSProof &P = out[j];
@@ -1540,7 +1802,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j], pf[j].d_a, 32, hipMemcpyDeviceToHost, s));
         BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j + 1], pf[j].d_b, 32, hipMemcpyDeviceToHost, s));
     }
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     const double ipp_ms = (now_ms() - t3) / (double)g, t_end = now_ms();
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
@@ -1556,7 +1818,10 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
 // =================================================================== Verifier
 
-Verifier::Verifier(const void *label, size_t label_len) : tr_(label, label_len) { tr_.r1cs_domain_sep(); }
+Verifier::Verifier(const void *label, size_t label_len) : tr_(label, label_len) {
+    tr_.r1cs_domain_sep();
+    if (auto e = last_shape(1)) follow(e->key, e);
+}
 
 Variable Verifier::commit(const uint8_t V32[32]) {
     uint32_t i = (uint32_t)(V_.size() / 32);
@@ -1565,13 +1830,11 @@ Variable Verifier::commit(const uint8_t V32[32]) {
     return Variable{VAR_COMMITTED, i};
 }
 
-ConstraintSystem::Triple Verifier::multiply(LinearCombination left, LinearCombination right) {
+ConstraintSystem::Triple Verifier::multiply(const LinearCombination &left, const LinearCombination &right) {
     uint32_t i = (uint32_t)num_vars_++;
     Triple t{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
-    left.terms.push_back({t.l, -Scalar(1)});
-    right.terms.push_back({t.r, -Scalar(1)});
-    cs_.push(left, num_vars_, V_.size() / 32);
-    cs_.push(right, num_vars_, V_.size() / 32);
+    cs_.push(left, num_vars_, V_.size() / 32, &t.l);
+    cs_.push(right, num_vars_, V_.size() / 32, &t.r);
     return t;
 }
 
@@ -1695,7 +1958,7 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk * 32, hipMemcpyDeviceToHost, s));
     if (m) BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
     if (n_one) BPG_CHECK_HIP(hipMemcpyAsync(h_one.data(), d_one, n_one * 32, hipMemcpyDeviceToHost, s));
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     Scalar delta(0), wc(0);
     for (size_t b = 0; b < nblk; b++) delta += Scalar(h_part[b]);
     for (size_t b = 0; b < n_one; b++) wc -= Scalar(h_one[b]);
@@ -1731,7 +1994,7 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
     if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
     BPG_CHECK_HIP(hipMemcpyAsync(d_tail, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipStreamSynchronize(s));
+    BPG_CHECK_HIP(lane_sync(lane));
     // d_gh = [g[0..ng) | h[0..nh)]: each rank takes the generators it holds; rank 0 adds the rest
     msm_seg gh[2] = {gen_seg(gens, 0, 0, ng, 0), gen_seg(gens, 1, 0, nh, ng)};
     msm_seg rest[2] = {{gens->table->d_table + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
@@ -1817,7 +2080,7 @@ int verify_batch(Verifier *const *vs, const R1CSProof *proofs, size_t k, Gens *g
         for (size_t i = 2; i < row.tail.size(); i++) tail.push_back((rho * Scalar(row.tail[i])).v);
         dyn.insert(dyn.end(), row.dyn.begin(), row.dyn.end());
         if (row.np > np_max) np_max = row.np;
-        BPG_CHECK_HIP(hipStreamSynchronize(s));     // the next prepare() reuses the lane's arena
+        BPG_CHECK_HIP(lane_sync(lane));     // the next prepare() reuses the lane's arena
     }
     tail[0] = accB.v;
     tail[1] = accBb.v;

@@ -331,13 +331,18 @@ int bpg_flat_cache_stats(bpg_ctx *ctx, uint64_t *hits, uint64_t *misses) {
 int bpg_cs_export_terms(const bpg_cs *cs, uint64_t *vars, uint8_t *coeffs32, uint32_t *constraint, size_t cap, size_t *n_terms) {
     if (!cs || !n_terms) return BPG_EINVAL;
     const ConstraintStore &st = cs->cs->store();
-    const size_t n = st.term_var.size();
+    // a store that follows a cached circuit holds its terms as a prefix of that circuit's lists
+    const bool fol = (bool)st.follow_key;
+    const uint32_t *tv = fol ? st.follow_key->term_var.data() : st.term_var.data();
+    const uint32_t *tc = fol ? st.follow_key->term_coeff.data() : st.term_coeff.data();
+    const uint32_t *tq = fol ? st.follow_key->term_q.data() : st.term_q.data();
+    const size_t n = st.nterms();
     *n_terms = n;
     if (cap < n || (n && (!vars || !coeffs32 || !constraint))) return BPG_EINVAL;
     for (size_t t = 0; t < n; t++) {
-        vars[t] = (uint64_t)(st.term_var[t] >> 28) << 32 | (st.term_var[t] & 0x0fffffffu);
-        sc_tobytes(coeffs32 + 32 * t, st.coeffs[st.term_coeff[t]]);
-        constraint[t] = st.term_q[t];
+        vars[t] = (uint64_t)(tv[t] >> 28) << 32 | (tv[t] & 0x0fffffffu);
+        sc_tobytes(coeffs32 + 32 * t, st.coeffs[tc[t]]);
+        constraint[t] = tq[t];
     }
     return BPG_OK;
 }

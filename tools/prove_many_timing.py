@@ -46,12 +46,17 @@ def main():
                          "poly_ms": round(sum(t["poly_ms"] for t in tm) / k, 2), "ipp_ms": round(sum(t["ipp_ms"] for t in tm) / k, 2)})
         res[tid] = rows[-1]
 
-    t0 = time.perf_counter()
+    t0, c0, o0 = time.perf_counter(), time.process_time(), os.times()
     th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
     [t.start() for t in th]
     [t.join() for t in th]
-    dt = time.perf_counter() - t0
-    print(json.dumps({"k": k, "threads": threads, "proofs_per_s_overall": round(3 * k * threads / dt, 1), "thread0": res[0]}))
+    dt, dc, o1 = time.perf_counter() - t0, time.process_time() - c0, os.times()
+    nproofs = 3 * k * threads
+    print(json.dumps({"k": k, "threads": threads, "proofs_per_s_overall": round(nproofs / dt, 1),
+                      "process_cpu_ms_per_proof": round(dc * 1e3 / nproofs, 2), "process_sys_ms_per_proof": round((o1.system - o0.system) * 1e3 / nproofs, 2),
+                      "thread0": res[0]}))
+    gens.free()
+    ctx.close()          # BPG_TRACE_HOST=1: the library prints its host-phase table here
 
 
 if __name__ == "__main__":
