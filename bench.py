@@ -249,8 +249,8 @@ def main():
     ap.add_argument("--logn", type=int, default=int(os.environ.get("BPG_BENCH_LOGN", "20")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-proofs", action="store_true", help="skip the secondary metric (R1CS proofs/s at 2^16 multipliers)")
-    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "48")))
-    ap.add_argument("--proofs-per-thread", type=int, default=32, help="per host thread, in calls of --proofs-per-call (long enough for the threads to fall out of step: host and GPU phases of different threads then overlap)")
+    ap.add_argument("--proof-threads", type=int, default=int(os.environ.get("BPG_BENCH_PROOF_THREADS", "64")))
+    ap.add_argument("--proofs-per-thread", type=int, default=24, help="per host thread, in calls of --proofs-per-call (long enough for the threads to fall out of step: host and GPU phases of different threads then overlap)")
     ap.add_argument("--proofs-per-call", type=int, default=8, help="statements per bpg_prover_prove_many call (1: plain prove calls)")
     ap.add_argument("--no-big-proof", action="store_true", help="skip the 2^20-multiplier proof (BASELINE configs[3])")
     ap.add_argument("--no-batch", action="store_true", help="skip the 4096-proof batch verification (BASELINE configs[4])")
@@ -430,7 +430,7 @@ def main():
                   "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
                   "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0][0] / cnt, "prove_and_verify": 1e3 * cpu_s3[0][1] / cnt,
                                             "prove_kernel_mode": 1e3 * cpu_s3[1][0] / cnt,
-                                            "note": "process CPU time (all host threads, spinning on stream synchronisation included) "
+                                            "note": "process CPU time (all host threads; waits sleep on the device's interrupt unless BPG_SYNC=spin) "
                                                     "of this rank's timed pass / proofs; the box gives a rank 16 cores"},
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
                               "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}

@@ -139,7 +139,7 @@ bpg_lane *lane_of(bpg_ctx *ctx) {
         delete lane;
         return nullptr;
     }
-    if (ctx->sync_block && ctx->sync_poll) {
+    if (ctx->sync_block) {
         e = hipEventCreateWithFlags(&lane->ev_sync, hipEventDisableTiming);
         if (e != hipSuccess) {
             set_last_error("hipEventCreateWithFlags(lane)", e);
@@ -191,24 +191,30 @@ void HostPhase::stop() {
 void HostPhase::report() {
     if (!enabled()) return;
     static const char *names[N] = {"capture_commit", "rng_begin", "rng_draw", "upload", "as_submit", "as_wait", "flatten_poly", "t_commit",
-                                   "ipp_rows", "ipp_submit", "ipp_wait", "ipp_host", "fold", "tail_host"};
+                                   "ipp_rows", "ipp_submit", "ipp_wait", "ipp_host", "fold", "tail_host", "gadget_calls"};
     fprintf(stderr, "[bpg host phases] %-16s %10s %12s %12s\n", "phase", "calls", "wall_ms", "thread_cpu_ms");
     for (int i = 0; i < N; i++)
         fprintf(stderr, "[bpg host phases] %-16s %10llu %12.1f %12.1f\n", names[i], (unsigned long long)g_phase_calls[i].load(),
                 g_phase_wall_us[i].load() / 1e3, g_phase_cpu_us[i].load() / 1e3);
 }
 
-// Waiting without burning a core.  What makes the HIP runtime sleep in its waits is the DEVICE's scheduling flag
-// (hipDeviceScheduleBlockingSync), which bpg_init sets when it can; hipEventBlockingSync on an event alone still
-// spins in user mode (measured: 36.6 ms of thread CPU per 2^16 proof against 12.1 with the device flag).  When
-// another library has already fixed the device's flags (ctx->sync_poll), the wait polls the event itself: a short
-// spin for waits that are nearly over, then naps.  BPG_SYNC=spin: the runtime's busy wait (lowest latency for one
-// proof alone; a prover service runs more threads than cores, and a spinning waiter takes a core from a thread
-// that captures or draws).
+// Waiting without burning a core, measured at 2^16-multiplier proofs:
+//  * spinning (the runtime's default; BPG_SYNC=spin): 36.6 ms of thread CPU per proof at 16 threads.  Lowest latency for
+//    one proof alone, but a prover service runs more threads than cores and a spinning waiter takes a core from a
+//    thread that captures or draws.
+//  * the device's scheduling flag hipDeviceScheduleBlockingSync (bpg_init sets it when the device still takes it)
+//    makes the runtime sleep on an interrupt: 0.9 ms of CPU per proof inside the waits at 24 threads -- but every
+//    completed kernel wakes every sleeper: 10.4 ms at 48 threads.  (hipEventBlockingSync on an event alone still
+//    spins in user mode.)
+//  * polling the event with naps of 20-100 us: 0.7 ms at 48 threads, and about 8 % fewer proofs/s than the interrupt
+//    (the path is latency-bound under load, and a nap overshoots).
+// Default: the interrupt (most proofs/s: 416-453 at 48-64 threads against 371-398 polling), polling where the device's
+// flags are already fixed; BPG_SYNC=poll / spin force those.  A hybrid (interrupt for the first 12-36 simultaneous
+// waiters, polling beyond) was within the run-to-run noise of the plain interrupt in proofs/s and cost more CPU.
 hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev) {
     if (!ctx->sync_block || !ctx->sync_poll) return hipEventSynchronize(ev);
     hipError_t e;
-    for (int spin = 0; spin < 200; spin++)
+    for (int spin = 0; spin < 20; spin++)
         if ((e = hipEventQuery(ev)) != hipErrorNotReady) return e;
     long ns = 20000;
     while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
@@ -220,7 +226,7 @@ hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev) {
 }
 hipError_t lane_sync(bpg_lane *lane) {
     const bpg_ctx *ctx = lane->ctx;
-    if (!ctx->sync_block || !ctx->sync_poll || !lane->ev_sync) return hipStreamSynchronize(lane->stream);
+    if (!ctx->sync_block || !lane->ev_sync) return hipStreamSynchronize(lane->stream);
     hipError_t e = hipEventRecord(lane->ev_sync, lane->stream);
     if (e != hipSuccess) return e;
     return wait_event(ctx, lane->ev_sync);
@@ -368,18 +374,15 @@ int bpg_init(int device_id, bpg_ctx **out) {
     bpg_ctx *ctx = new bpg_ctx();
     ctx->sync_block = sync_block;
     if (sync_block) {
+        // the device flag makes the waits INSIDE the runtime sleep too (pageable copies, allocation); it is refused once
+        // the device is in use with other flags, and the library's own waits then poll
         const char *mode = getenv("BPG_SYNC");
         unsigned flags = 0;
-        bool took = false;
-        if (!(mode && !strcmp(mode, "poll"))) {                       // BPG_SYNC=poll: the fallback below, on request (tests)
-            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);  // refused once the device is in use with other flags
-            (void)hipGetLastError();
-            took = hipGetDeviceFlags(&flags) == hipSuccess && (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync;
-        }
-        ctx->sync_poll = !took;
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        (void)hipGetLastError();
+        const bool took = hipGetDeviceFlags(&flags) == hipSuccess && (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync;
+        ctx->sync_poll = !took || (mode && !strcmp(mode, "poll"));
     }
-    ctx->device = device_id;
-    ctx->id = g_next_ctx_id.fetch_add(1);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
@@ -406,6 +409,9 @@ int bpg_init(int device_id, bpg_ctx **out) {
 void bpg_shutdown(bpg_ctx *ctx) {
     if (!ctx) return;
     HostPhase::report();
+    if (HostPhase::enabled())
+        fprintf(stderr, "[bpg host phases] circuit-structure cache: %llu hits (%llu by following the cached circuit during capture), %llu misses\n",
+                (unsigned long long)ctx->flat_hits.load(), (unsigned long long)ctx->flat_followed.load(), (unsigned long long)ctx->flat_misses.load());
     (void)hipSetDevice(ctx->device);
     // no call may be in flight on any thread; lanes of threads that have exited are freed here too
     {

@@ -120,7 +120,7 @@ struct bpg_msm_job {
 struct bpg_lane {
     bpg_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;     // setup / codec / scalar-vector kernel stream
-    hipEvent_t ev_sync = nullptr;     // polled waits on `stream` (lane_sync); null unless ctx->sync_poll
+    hipEvent_t ev_sync = nullptr;     // waits on `stream` go through this event (lane_sync); null when the context spins
     std::vector<bpg_msm_job *> jobs;  // MSM job pool (each job has its own stream)
     float last_acc_us = 0.f, last_total_us = 0.f;
     bpg_msm_job *acc_gate_job = nullptr;   // job whose accumulate pass was submitted last (its ev[2] gates the next one)
@@ -156,7 +156,7 @@ struct bpg_ctx {
     bpg::msm_tuning tune;
     int resident_lanes = 262144;      // CUs x 4 SIMDs x 4 waves x 64 lanes: threads of k_accumulate resident at once
     bool sync_block = true;           // waits sleep instead of spinning; BPG_SYNC=spin clears it
-    bool sync_poll = false;           // the device's blocking-sync flag could not be set: waits poll and nap (api.hip: wait_event)
+    bool sync_poll = false;           // waits always poll and nap (BPG_SYNC=poll, or the device's blocking-sync flag could not be set)
     std::mutex mu;                    // guards lanes, free_lanes
     std::vector<bpg_lane *> lanes;
     std::vector<bpg_lane *> free_lanes;   // lanes of threads that have exited: the next new thread takes one over
@@ -176,7 +176,7 @@ namespace bpg {
 // summed over all threads.  Where a prover thread's time goes under load cannot be read off a GPU trace.
 struct HostPhase {
     enum Id { CAPTURE_COMMIT, RNG_BEGIN, RNG_DRAW, UPLOAD, AS_SUBMIT, AS_WAIT, FLATTEN_POLY, T_COMMIT, IPP_ROWS, IPP_SUBMIT, IPP_WAIT, IPP_HOST,
-              FOLD, TAIL_HOST, N };
+              FOLD, TAIL_HOST, GADGET, N };
     static bool enabled();
     static void add(Id id, double wall_ms, double cpu_ms);
     static void report();

@@ -62,108 +62,188 @@ struct Term {
     Scalar coeff;
 };
 
-// Terms of a linear combination: the gadgets build tens of thousands of short-lived LCs with one to
-// five terms each, so the first INLINE terms live inside the object (no heap traffic during capture).
-class TermVec {
+// A linear combination as the gadgets build them: tens of thousands of short-lived objects with one to six terms each,
+// nearly all with coefficient +1 or -1 (ref: src/gadgets/point/edwards_point.rs:55-79: sums and differences of
+// wires).  A term is therefore 8 bytes -- the variable packed as kind << 28 | index and a small signed coefficient --
+// and only a coefficient that is not a small integer (a public coordinate, the curve constant d) takes a 32-byte
+// slot in a side table, in order of appearance.  Negating or copying a term of +-1 is integer work; capture
+// evaluates and compares such terms without touching a scalar.  Up to INL terms and INL_BIG large coefficients live
+// inside the object; beyond that everything moves to the heap.
+class LinearCombination {
   public:
-    static constexpr uint32_t INLINE = 6;
-    TermVec() {}
-    TermVec(const TermVec &o) { assign(o); }
-    TermVec(TermVec &&o) noexcept { steal(o); }
-    TermVec &operator=(const TermVec &o) {
-        if (this != &o) {
-            n_ = 0;
-            assign(o);
-        }
-        return *this;
+    struct Entry {
+        uint32_t var;       // kind << 28 | index
+        int32_t k;          // the coefficient if it is a small integer (|k| < 2^30), else BIG: the next slot of the side table
+    };
+    static constexpr int32_t BIG = INT32_MIN;
+    static constexpr uint32_t INL = 7, INL_BIG = 4;
+
+    LinearCombination() {}
+    LinearCombination(const Variable &v) {
+        e_[0] = Entry{v.kind << 28 | v.index, 1};
+        n_ = 1;
     }
-    TermVec &operator=(TermVec &&o) noexcept {
+    LinearCombination(const Scalar &s) { push(Variable::One(), s); }
+    LinearCombination(const LinearCombination &o) { copy_from(o); }
+    LinearCombination(LinearCombination &&o) noexcept {
+        copy_inline(o);
+        h_ = o.h_;
+        o.h_ = nullptr;
+        o.n_ = o.nbig_ = 0;
+    }
+    LinearCombination &operator=(const LinearCombination &o) {
         if (this != &o) {
             release();
-            steal(o);
+            copy_from(o);
         }
         return *this;
     }
-    ~TermVec() { release(); }
-    size_t size() const { return n_; }
-    const Term *begin() const { return data(); }
-    const Term *end() const { return data() + n_; }
-    const Term &operator[](size_t i) const { return data()[i]; }
-    void reserve(size_t want) {
-        if (want > cap_) grow(want);
-    }
-    void push_back(const Term &t) {
-        if (n_ == cap_) grow((size_t)cap_ * 2);
-        data()[n_++] = t;
-    }
-    void append(const TermVec &o) {
-        const uint32_t m = o.n_;                 // (o may be *this)
-        reserve((size_t)n_ + m);
-        memmove(static_cast<void *>(data() + n_), o.data(), m * sizeof(Term));
-        n_ += m;
-    }
-
-  private:
-    // raw storage: a Term is trivially copyable, and constructing six of them (zeroed coefficients) for every
-    // short-lived linear combination was a quarter of the capture time
-    Term *inl() { return reinterpret_cast<Term *>(inl_); }
-    const Term *inl() const { return reinterpret_cast<const Term *>(inl_); }
-    Term *data() { return heap_ ? heap_ : inl(); }
-    const Term *data() const { return heap_ ? heap_ : inl(); }
-    void grow(size_t want) {
-        Term *nw = static_cast<Term *>(::operator new(want * sizeof(Term)));
-        memcpy(static_cast<void *>(nw), data(), n_ * sizeof(Term));
-        ::operator delete(heap_);
-        heap_ = nw;
-        cap_ = (uint32_t)want;
-    }
-    void assign(const TermVec &o) {
-        reserve(o.n_);
-        memcpy(static_cast<void *>(data()), o.data(), o.n_ * sizeof(Term));
-        n_ = o.n_;
-    }
-    void steal(TermVec &o) {
-        if (o.heap_) {
-            heap_ = o.heap_;
-            cap_ = o.cap_;
-            o.heap_ = nullptr;
-            o.cap_ = INLINE;
-        } else {
-            heap_ = nullptr;
-            cap_ = INLINE;
-            memcpy(static_cast<void *>(inl_), o.inl_, o.n_ * sizeof(Term));
+    LinearCombination &operator=(LinearCombination &&o) noexcept {
+        if (this != &o) {
+            release();
+            copy_inline(o);
+            h_ = o.h_;
+            o.h_ = nullptr;
+            o.n_ = o.nbig_ = 0;
         }
-        n_ = o.n_;
-        o.n_ = 0;
+        return *this;
     }
-    void release() {
-        ::operator delete(heap_);
-        heap_ = nullptr;
-        cap_ = INLINE;
-        n_ = 0;
-    }
-    alignas(8) unsigned char inl_[INLINE * (sizeof(Variable) + sizeof(sc))];
-    Term *heap_ = nullptr;
-    uint32_t n_ = 0, cap_ = INLINE;
-};
-static_assert(sizeof(Term) == sizeof(Variable) + sizeof(sc), "TermVec's inline storage is sized from the parts of a Term");
+    ~LinearCombination() { release(); }
 
-struct LinearCombination {
-    TermVec terms;
-    LinearCombination() {}
-    LinearCombination(const Variable &v) { terms.push_back({v, Scalar(1)}); }
-    LinearCombination(const Scalar &s) { terms.push_back({Variable::One(), s}); }
+    size_t size() const { return n_; }
+    size_t num_big() const { return nbig_; }
+    const Entry *entries() const { return h_ ? h_->e.data() : e_; }
+    const sc *bigs() const { return h_ ? h_->big.data() : big_; }
+
+    // small integer value of a scalar (|k| < 2^30: k or l - |k|), else BIG
+    static int32_t small_of(const sc &c) {
+        if ((c.v[1] | c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7]) == 0) return c.v[0] < (1u << 30) ? (int32_t)c.v[0] : BIG;
+        // l - x, 0 < x < 2^30: only the lowest limb differs from l's (l's lowest limb is 0x5cf5d3ed > 2^30: no borrow)
+        if (c.v[7] == 0x10000000u && (c.v[4] | c.v[5] | c.v[6]) == 0 && c.v[3] == 0x14def9deu && c.v[2] == 0xa2f79cd6u &&
+            c.v[1] == 0x5812631au && c.v[0] < 0x5cf5d3edu && 0x5cf5d3edu - c.v[0] < (1u << 30))
+            return -(int32_t)(0x5cf5d3edu - c.v[0]);
+        return BIG;
+    }
+    static sc scalar_of(int32_t k) {
+        sc r = sc_from_u64((uint64_t)(k < 0 ? -(int64_t)k : (int64_t)k));
+        if (k < 0) sc_neg(r, r);
+        return r;
+    }
+    void push(const Variable &v, const Scalar &c) {
+        const int32_t k = small_of(c.v);
+        if (k != BIG) push_small(v.kind << 28 | v.index, k);
+        else push_big(v.kind << 28 | v.index, c.v);
+    }
+    void reserve(size_t terms) {
+        if (terms > INL) to_heap(terms);
+    }
+    // the i-th term, materialized (tests, export; capture walks entries() / bigs() instead)
+    Term term(size_t i) const {
+        const Entry *e = entries();
+        size_t b = 0;
+        for (size_t j = 0; j < i; j++) b += e[j].k == BIG;
+        const Variable v{e[i].var >> 28, e[i].var & 0x0fffffffu};
+        return Term{v, e[i].k == BIG ? Scalar(bigs()[b]) : Scalar(scalar_of(e[i].k))};
+    }
+
     LinearCombination &operator+=(const LinearCombination &o) {
-        terms.append(o.terms);
+        append(o, false);
         return *this;
     }
     LinearCombination &operator-=(const LinearCombination &o) {
-        for (const auto &t : o.terms) terms.push_back({t.var, -t.coeff});
+        append(o, true);
         return *this;
     }
-    LinearCombination operator+(const LinearCombination &o) const { LinearCombination r = *this; r += o; return r; }
-    LinearCombination operator-(const LinearCombination &o) const { LinearCombination r = *this; r -= o; return r; }
-    LinearCombination operator-() const { LinearCombination r; r -= *this; return r; }
+    LinearCombination operator+(const LinearCombination &o) const { LinearCombination r = *this; r.append(o, false); return r; }
+    LinearCombination operator-(const LinearCombination &o) const { LinearCombination r = *this; r.append(o, true); return r; }
+    LinearCombination operator-() const { LinearCombination r; r.append(*this, true); return r; }
+
+  private:
+    struct Heap {
+        std::vector<Entry> e;
+        std::vector<sc> big;
+    };
+    void copy_inline(const LinearCombination &o) {
+        n_ = o.n_;
+        nbig_ = o.nbig_;
+        if (!o.h_) {
+            memcpy(e_, o.e_, o.n_ * sizeof(Entry));
+            memcpy(static_cast<void *>(big_), o.big_, o.nbig_ * sizeof(sc));
+        }
+    }
+    void copy_from(const LinearCombination &o) {
+        copy_inline(o);
+        h_ = o.h_ ? new Heap(*o.h_) : nullptr;
+    }
+    void release() {
+        delete h_;
+        h_ = nullptr;
+        n_ = nbig_ = 0;
+    }
+    void to_heap(size_t want_terms) {
+        if (!h_) {
+            h_ = new Heap();
+            h_->e.assign(e_, e_ + n_);
+            h_->big.assign(big_, big_ + nbig_);
+        }
+        h_->e.reserve(want_terms);
+    }
+    void push_small(uint32_t var, int32_t k) {
+        if (h_) {
+            h_->e.push_back(Entry{var, k});
+        } else if (n_ < INL) {
+            e_[n_] = Entry{var, k};
+        } else {
+            to_heap(2 * INL);
+            h_->e.push_back(Entry{var, k});
+        }
+        n_++;
+    }
+    void push_big(uint32_t var, const sc &c) {
+        if (!h_ && (n_ >= INL || nbig_ >= INL_BIG)) to_heap(2 * INL);
+        if (h_) {
+            h_->e.push_back(Entry{var, BIG});
+            h_->big.push_back(c);
+        } else {
+            e_[n_] = Entry{var, BIG};
+            big_[nbig_] = c;
+        }
+        n_++;
+        nbig_++;
+    }
+    // *this += o or *this -= o (o may be *this)
+    void append(const LinearCombination &o, bool negate) {
+        const uint32_t m = o.n_, mb = o.nbig_;
+        if (!h_ && !o.h_ && n_ + m <= INL && nbig_ + mb <= INL_BIG) {          // the common case: all inline
+            for (uint32_t i = 0; i < m; i++) {
+                const Entry t = o.e_[i];
+                e_[n_ + i] = Entry{t.var, negate && t.k != BIG ? -t.k : t.k};
+            }
+            for (uint32_t i = 0; i < mb; i++) {
+                if (negate) sc_neg(big_[nbig_ + i], o.big_[i]);
+                else big_[nbig_ + i] = o.big_[i];
+            }
+            n_ += m;
+            nbig_ += mb;
+            return;
+        }
+        to_heap((size_t)n_ + m);
+        std::vector<Entry> oe(o.entries(), o.entries() + m);               // (copies: o may be *this, and the vectors may move)
+        std::vector<sc> ob(o.bigs(), o.bigs() + mb);
+        for (const Entry &t : oe) h_->e.push_back(Entry{t.var, negate && t.k != BIG ? -t.k : t.k});
+        for (const sc &c : ob) {
+            sc x = c;
+            if (negate) sc_neg(x, c);
+            h_->big.push_back(x);
+        }
+        n_ += m;
+        nbig_ += mb;
+    }
+
+    uint32_t n_ = 0, nbig_ = 0;
+    Entry e_[INL];
+    sc big_[INL_BIG];
+    Heap *h_ = nullptr;
 };
 using LC = LinearCombination;
 
@@ -194,7 +274,9 @@ struct ConstraintStore {
     std::unordered_map<uint64_t, std::vector<uint32_t>> coeff_lookup;   // hash -> ids
     uint32_t num_constraints = 0;
     uint32_t id_one = 0xffffffffu, id_minus_one = 0xffffffffu;       // almost every coefficient is +1 or -1
+    std::vector<int32_t> small_of_id;    // per coefficient id: its value as a small integer, or LinearCombination::BIG
     uint32_t intern(const sc &c);
+    uint32_t intern_small(int32_t k);    // intern(LinearCombination::scalar_of(k)), without building the scalar for +-1
     // n_mult / n_commit: multipliers allocated and values committed so far; a term outside them throws
     // R1CSError(BPG_EINVAL) (a gadget built from another constraint system's variables).  minus_var: one more
     // term (minus_var, -1) after lc's (the implicit constraint of a multiply: lc - wire = 0).

@@ -466,36 +466,40 @@ __global__ void __launch_bounds__(64) k_build_comb(const aniels_rec *__restrict_
 uint32_t ConstraintStore::intern(const sc &c) {
     static const sc one = sc_one();
     static const sc minus_one = (-Scalar(1)).v;
-    if (sc_eq(c, one)) {
-        if (id_one == 0xffffffffu) {
-            coeffs.push_back(c);
-            id_one = (uint32_t)coeffs.size() - 1;
-        }
-        return id_one;
-    }
-    if (sc_eq(c, minus_one)) {
-        if (id_minus_one == 0xffffffffu) {
-            coeffs.push_back(c);
-            id_minus_one = (uint32_t)coeffs.size() - 1;
-        }
-        return id_minus_one;
-    }
+    if (sc_eq(c, one)) return intern_small(1);
+    if (sc_eq(c, minus_one)) return intern_small(-1);
     uint64_t h = ((uint64_t)c.v[1] << 32 | c.v[0]) ^ ((uint64_t)c.v[7] << 32 | c.v[4]) * 0x9e3779b97f4a7c15ULL;
     auto &ids = coeff_lookup[h];
     for (uint32_t id : ids)
         if (sc_eq(coeffs[id], c)) return id;
     coeffs.push_back(c);
+    small_of_id.push_back(LinearCombination::small_of(c));
     ids.push_back((uint32_t)coeffs.size() - 1);
     return (uint32_t)coeffs.size() - 1;
 }
 
-static const sc k_minus_one = (-Scalar(1)).v;
+uint32_t ConstraintStore::intern_small(int32_t k) {
+    uint32_t *slot = k == 1 ? &id_one : k == -1 ? &id_minus_one : nullptr;
+    if (!slot) return intern(LinearCombination::scalar_of(k));
+    if (*slot == 0xffffffffu) {
+        coeffs.push_back(LinearCombination::scalar_of(k));
+        small_of_id.push_back(k);
+        *slot = (uint32_t)coeffs.size() - 1;
+    }
+    return *slot;
+}
+
+static inline bool var_in_range(uint32_t packed, size_t n_mult, size_t n_commit) {
+    const uint32_t kind = packed >> 28, index = packed & 0x0fffffffu;
+    const size_t lim = kind == VAR_COMMITTED ? n_commit : kind == VAR_ONE ? 1 : kind <= VAR_OUTPUT ? n_mult : 0;
+    return index < lim;
+}
 
 void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_commit, const Variable *minus_var) {
-    for (const auto &t : lc.terms) {
-        const size_t lim = t.var.kind == VAR_COMMITTED ? n_commit : t.var.kind == VAR_ONE ? 1 : t.var.kind <= VAR_OUTPUT ? n_mult : 0;
-        if (t.var.index >= lim) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
-    }
+    const LinearCombination::Entry *e = lc.entries();
+    const size_t n = lc.size();
+    for (size_t i = 0; i < n; i++)
+        if (!var_in_range(e[i].var, n_mult, n_commit)) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
     if (follow_key) {
         if (push_follow(lc, minus_var)) {
             num_constraints++;
@@ -503,14 +507,15 @@ void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_
         }
         materialize();
     }
-    for (const auto &t : lc.terms) {
-        term_var.push_back(t.var.kind << 28 | t.var.index);
-        term_coeff.push_back(intern(t.coeff.v));
+    const sc *big = lc.bigs();
+    for (size_t i = 0; i < n; i++) {
+        term_var.push_back(e[i].var);
+        term_coeff.push_back(e[i].k != LinearCombination::BIG ? intern_small(e[i].k) : intern(*big++));
         term_q.push_back(num_constraints);
     }
     if (minus_var) {
         term_var.push_back(minus_var->kind << 28 | minus_var->index);
-        term_coeff.push_back(intern(k_minus_one));
+        term_coeff.push_back(intern_small(-1));
         term_q.push_back(num_constraints);
     }
     num_constraints++;
@@ -525,27 +530,38 @@ void ConstraintStore::push(const LinearCombination &lc, size_t n_mult, size_t n_
 // would have interned at the same point.
 bool ConstraintStore::push_follow(const LinearCombination &lc, const Variable *minus_var) {
     const CircuitKey &k = *follow_key;
-    const size_t nk = k.term_var.size(), len = lc.terms.size() + (minus_var ? 1 : 0), end = cur + len;
+    const size_t nk = k.term_var.size(), len = lc.size() + (minus_var ? 1 : 0), end = cur + len;
     const uint32_t q = num_constraints;
     if (end > nk) return false;
     if (len && (k.term_q[cur] != q || k.term_q[end - 1] != q)) return false;
     if (end < nk && k.term_q[end] == q) return false;
     const uint32_t *kv = k.term_var.data() + cur, *kc = k.term_coeff.data() + cur;
+    const LinearCombination::Entry *e = lc.entries();
+    const sc *big = lc.bigs();
+    const size_t n = lc.size();
     size_t i = 0;
-    for (const auto &t : lc.terms) {
-        if (kv[i] != (t.var.kind << 28 | t.var.index)) return false;
+    for (; i < n; i++) {
+        if (kv[i] != e[i].var) return false;
         const uint32_t id = kc[i];
-        if (id < coeffs.size()) {
-            if (!sc_eq(coeffs[id], t.coeff.v)) return false;
-        } else if (id != coeffs.size() || intern(t.coeff.v) != id) {
-            return false;
+        if (e[i].k != LinearCombination::BIG) {
+            if (id < coeffs.size()) {
+                if (small_of_id[id] != e[i].k) return false;
+            } else if (id != coeffs.size() || intern_small(e[i].k) != id) {
+                return false;
+            }
+        } else {
+            const sc &c = *big++;
+            if (id < coeffs.size()) {
+                if (!sc_eq(coeffs[id], c)) return false;
+            } else if (id != coeffs.size() || intern(c) != id) {
+                return false;
+            }
         }
-        i++;
     }
     if (minus_var) {
         if (kv[i] != (minus_var->kind << 28 | minus_var->index)) return false;
         const uint32_t id = kc[i];
-        if (id != id_minus_one && (id != coeffs.size() || intern(k_minus_one) != id)) return false;
+        if (id != id_minus_one && (id != coeffs.size() || intern_small(-1) != id)) return false;
     }
     cur = end;
     return true;
@@ -1106,27 +1122,40 @@ void Prover::commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, u
 }
 
 Scalar Prover::eval(const LinearCombination &lc) const {
-    static const sc one = sc_one();
-    static const sc minus_one = (-Scalar(1)).v;
-    Scalar acc(0);
-    for (const auto &t : lc.terms) {
+    const LinearCombination::Entry *e = lc.entries();
+    const sc *big = lc.bigs();
+    const size_t n = lc.size(), nm = a_L_.size(), nc = v_.size();
+    sc acc = sc_zero();
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t kind = e[i].var >> 28, index = e[i].var & 0x0fffffffu;
+        const int32_t k = e[i].k;
         const sc *val;
-        const size_t lim = t.var.kind == VAR_COMMITTED ? v_.size() : t.var.kind == VAR_ONE ? 1 : t.var.kind <= VAR_OUTPUT ? a_L_.size() : 0;
-        if (t.var.index >= lim) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
-        switch (t.var.kind) {
-            case VAR_LEFT: val = &a_L_[t.var.index]; break;
-            case VAR_RIGHT: val = &a_R_[t.var.index]; break;
-            case VAR_OUTPUT: val = &a_O_[t.var.index]; break;
-            case VAR_COMMITTED: val = &v_[t.var.index]; break;
-            default: val = &one; break;
+        switch (kind) {
+            case VAR_LEFT: val = index < nm ? &a_L_[index] : nullptr; break;
+            case VAR_RIGHT: val = index < nm ? &a_R_[index] : nullptr; break;
+            case VAR_OUTPUT: val = index < nm ? &a_O_[index] : nullptr; break;
+            case VAR_COMMITTED: val = index < nc ? &v_[index] : nullptr; break;
+            case VAR_ONE: {                              // a constant: the coefficient itself
+                if (index != 0) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
+                if (k == LinearCombination::BIG) sc_add(acc, acc, *big++);
+                else sc_add(acc, acc, LinearCombination::scalar_of(k));
+                continue;
+            }
+            default: val = nullptr;
         }
+        if (!val) throw R1CSError(BPG_EINVAL, "variable does not belong to this constraint system");
         // almost every coefficient in the gadget circuits is +1 or -1: no multiplication then
-        if (sc_eq(t.coeff.v, one)) acc += Scalar(*val);
-        else if (sc_eq(t.coeff.v, minus_one)) acc -= Scalar(*val);
-        else if (val == &one) acc += t.coeff;
-        else acc += t.coeff * Scalar(*val);
+        if (k == 1) {
+            sc_add(acc, acc, *val);
+        } else if (k == -1) {
+            sc_sub(acc, acc, *val);
+        } else {
+            sc t;
+            sc_mul(t, k == LinearCombination::BIG ? *big++ : LinearCombination::scalar_of(k), *val);
+            sc_add(acc, acc, t);
+        }
     }
-    return acc;
+    return Scalar(acc);
 }
 
 ConstraintSystem::Triple Prover::multiply(const LinearCombination &left, const LinearCombination &right) {

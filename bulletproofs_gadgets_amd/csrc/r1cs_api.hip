@@ -56,8 +56,8 @@ Variable checked_var(const ConstraintSystem &cs, uint64_t packed) {
 LC unpack_lc(const ConstraintSystem &cs, const uint64_t *vars, const uint8_t *coeffs, size_t n) {
     if (n && (!vars || !coeffs)) throw R1CSError(BPG_EINVAL, "linear combination: null arrays");
     LC lc;
-    lc.terms.reserve(n);
-    for (size_t i = 0; i < n; i++) lc.terms.push_back({checked_var(cs, vars[i]), sc_in(coeffs + 32 * i)});
+    lc.reserve(n);
+    for (size_t i = 0; i < n; i++) lc.push(checked_var(cs, vars[i]), sc_in(coeffs + 32 * i));
     return lc;
 }
 
@@ -414,6 +414,7 @@ int bpg_edwards_conditionally_select(bpg_cs *cs, const bpg_point_gadget *a, cons
 int bpg_edwards_scalar_mul(bpg_cs *cs, const bpg_point_gadget *point, const uint64_t *sk_vars, size_t nbits, bpg_point_gadget **out) {
     if (!cs || !point || !out || (nbits && !sk_vars)) return BPG_EINVAL;
     return guarded([&] {
+        HostPhase hp(HostPhase::GADGET);
         std::vector<Variable> sk(nbits);
         for (size_t i = 0; i < nbits; i++) sk[i] = checked_var(*cs->cs, sk_vars[i]);
         auto r = SonnyEdwardsPointGadget::scalar_mul(E_OF(point), sk, *cs->cs);

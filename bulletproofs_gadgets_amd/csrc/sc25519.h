@@ -205,6 +205,88 @@ inline void sc_montmul_host64(sc &r, const sc &a, const sc &b) {
         r.v[2 * i + 1] = (uint32_t)(w >> 32);
     }
 }
+
+// Host form of a*b mod l in one pass (plain in, plain out): a 4x4 product of 64-bit limbs, then three folds of the
+// part above bit 252 with 2^252 = -c (mod l), c = l - 2^252 < 2^125 (two limbs):
+//   P = q 2^252 + lo;  q c = th 2^252 + t_lo;  th c = uh 2^252 + u_lo;  P = lo - t_lo + u_lo - uh c   (mod l)
+// 16 + 10 + 6 + 2 = 34 multiplications where two Montgomery passes take 64.  Circuit capture spends half of its time
+// here (one product per multiplier), the transcript's challenges and the prover's scalars the rest.
+inline void sc_mul_host64(sc &r, const sc &a, const sc &b) {
+    typedef unsigned __int128 u128;
+    const uint64_t C0 = 0x5812631a5cf5d3edULL, C1 = 0x14def9dea2f79cd6ULL, M60 = (1ULL << 60) - 1;
+    uint64_t A[4], B[4], P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    }
+    for (int i = 0; i < 4; i++) {
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {
+            const u128 acc = (u128)A[i] * B[j] + P[i + j] + carry;
+            P[i + j] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        P[i + 4] = carry;
+    }
+    // x (n limbs) * c -> n + 2 limbs
+    auto mul_c = [&](uint64_t *out, const uint64_t *x, int n) {
+        uint64_t carry = 0;
+        for (int k = 0; k < n; k++) {
+            const u128 acc = (u128)x[k] * C0 + carry;
+            out[k] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        out[n] = carry;
+        out[n + 1] = 0;
+        carry = 0;
+        for (int k = 0; k < n; k++) {
+            const u128 acc = (u128)x[k] * C1 + out[k + 1] + carry;
+            out[k + 1] = (uint64_t)acc;
+            carry = (uint64_t)(acc >> 64);
+        }
+        out[n + 1] += carry;
+    };
+    uint64_t q[5], t[8], th[3], u[6], w[3];
+    for (int k = 0; k < 5; k++) q[k] = (P[3 + k] >> 60) | (P[4 + k] << 4);          // P >> 252 (P[8] = 0)
+    mul_c(t, q, 5);                                                                 // < 2^385: 7 limbs
+    t[7] = 0;
+    for (int k = 0; k < 3; k++) th[k] = (t[3 + k] >> 60) | (t[4 + k] << 4);         // < 2^133
+    mul_c(u, th, 3);                                                                // < 2^258: 5 limbs
+    const uint64_t uh = (u[3] >> 60) | (u[4] << 4);                                 // < 2^6
+    {
+        const u128 w0 = (u128)uh * C0, w1 = (u128)uh * C1 + (uint64_t)(w0 >> 64);
+        w[0] = (uint64_t)w0;
+        w[1] = (uint64_t)w1;
+        w[2] = (uint64_t)(w1 >> 64);
+    }
+    // v = lo + u_lo + 2 l - t_lo - uh c   in (0, 4 l)
+    const uint64_t lo[4] = {P[0], P[1], P[2], P[3] & M60}, tl[4] = {t[0], t[1], t[2], t[3] & M60}, ul[4] = {u[0], u[1], u[2], u[3] & M60};
+    const uint64_t L2[4] = {C0 << 1, (C1 << 1) | (C0 >> 63), 0, 1ULL << 61}, L1[4] = {C0, C1, 0, 1ULL << 60}, wl[4] = {w[0], w[1], w[2], 0};
+    uint64_t v[4];
+    __int128 acc = 0;
+    for (int k = 0; k < 4; k++) {
+        acc += (__int128)lo[k] + ul[k] + L2[k];
+        acc -= (__int128)tl[k] + wl[k];
+        v[k] = (uint64_t)acc;
+        acc >>= 64;
+    }
+    for (int pass = 0; pass < 2; pass++) {                                          // v >= 2 l ? v -= 2 l;  v >= l ? v -= l
+        const uint64_t *m = pass == 0 ? L2 : L1;
+        uint64_t d[4];
+        __int128 bw = 0;
+        for (int k = 0; k < 4; k++) {
+            bw += (__int128)v[k] - m[k];
+            d[k] = (uint64_t)bw;
+            bw >>= 64;
+        }
+        if (bw == 0)
+            for (int k = 0; k < 4; k++) v[k] = d[k];
+    }
+    for (int i = 0; i < 4; i++) {
+        r.v[2 * i] = (uint32_t)v[i];
+        r.v[2 * i + 1] = (uint32_t)(v[i] >> 32);
+    }
+}
 #endif
 
 // a*b/R mod l
@@ -222,9 +304,13 @@ BPG_HD void sc_from_mont(sc &r, const sc &a) { sc_montmul(r, a, sc_one()); }
 
 // plain * plain -> plain
 BPG_HD void sc_mul(sc &r, const sc &a, const sc &b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    sc_mul_host64(r, a, b);
+#else
     sc t;
     sc_montmul(t, a, b);
     sc_montmul(r, t, sc_rr());
+#endif
 }
 // r = a*b + c
 BPG_HD void sc_muladd(sc &r, const sc &a, const sc &b, const sc &c) {

@@ -76,6 +76,27 @@ def test_scalar_ops(host_hooks, golden):
         assert o.raw.hex() == v["out"]
 
 
+def test_scalar_mul_one_pass_reduction(host_hooks):
+    """the host's a*b mod l folds the product above bit 252 three times (sc25519.h: sc_mul_host64): values at the
+    edges of every fold -- products just below and above multiples of 2^252, operands up to 2^256 - 1 (callers pass
+    canonical scalars, the arithmetic must hold for any 256-bit string) -- and 20 000 random pairs"""
+    H = host_hooks
+    rnd = random.Random(77)
+    o = ctypes.create_string_buffer(32)
+    C = L - 2**252
+    edge = [0, 1, 2, L - 1, L - 2, L, L + 1, 2**252, 2**252 - 1, 2**252 + 1, C, C - 1, C + 1, 2**255 - 19, 2**256 - 1, 2**256 - 2, 2**128,
+            2**128 - 1, 2**192, (L - 1) // 2, (L + 1) // 2, 2**253 - 1, 2**64 - 1, 2**64]
+    for a in edge:
+        for b in edge:
+            H.hh_sc_mul(o, B(a), B(b))
+            assert I(o) == a * b % L, (hex(a), hex(b))
+    for _ in range(20000):
+        bits_a, bits_b = rnd.choice((64, 125, 126, 200, 252, 253, 256)), rnd.choice((64, 125, 126, 200, 252, 253, 256))
+        a, b = rnd.getrandbits(bits_a), rnd.getrandbits(bits_b)
+        H.hh_sc_mul(o, B(a), B(b))
+        assert I(o) == a * b % L, (hex(a), hex(b))
+
+
 def test_ristretto_codec_and_group_ops(host_hooks, golden):
     H = host_hooks
     o = ctypes.create_string_buffer(32)
