@@ -27,6 +27,8 @@ import time
 # run in submission order, and a stream parked on the accumulate gate then holds up the others behind it.
 # (read by the HIP runtime when it starts, so set before anything loads it)
 os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("BPG_BENCH_HW_QUEUES", "8")
+# a proof that is proved alone (the latency leg) times its scalar-vector kernels with HIP events: secondary.scalar_kernels
+os.environ.setdefault("BPG_TIME_KERNELS", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -99,6 +101,28 @@ def proof_algorithmic_macs(lg):
     return pts * 20 * 504, pts
 
 
+def scalar_kernel_report(ktimes):
+    """HBM GB/s of the scalar-vector kernels (l(x) / r(x) / t(x) algebra and the inner-product folding) of one
+    2^16-multiplier proof proved alone, from HIP events on their dispatches (bpg_prover_kernel_timing; median of the
+    single-proof legs), against both ceilings: bytes / 8 TB/s, and multiplications mod l (one Montgomery pass = 104
+    v_mad_u64_u32) / the multiply-add peak.  `bound` names the larger of the two fractions."""
+    if not ktimes:
+        return None
+    out = {}
+    for name in ktimes[0]:
+        us = sorted(k[name][0] for k in ktimes)[len(ktimes) // 2]
+        _, nbytes, mm = ktimes[0][name]
+        if us <= 0:
+            continue
+        gbps, gmacs = nbytes / us / 1e3, mm * 104 / us / 1e3
+        out[name] = {"us": round(us, 1), "bytes": int(nbytes), "GBps": round(gbps, 1), "hbm_frac": round(gbps / 8000.0, 4),
+                     "montmul": int(mm), "GMACps": round(gmacs, 1), "valu_mac_frac": round(gmacs / VMAD_PEAK_GMACS, 4),
+                     "bound": "valu_int32 (mod-l multiplications)" if gmacs / VMAD_PEAK_GMACS > gbps / 8000.0 else "hbm"}
+    out["note"] = ("one proof alone (the kernels of a group of eight are eight times as large); k_ipp_rows / k_ipp_fold: first inner-product "
+                   "round; bytes = every input read once + every output written once")
+    return out
+
+
 PROOF_BITS = 2427        # SURVEY.md 8(d) cfg3: 27 * 2427 + 4 = 65 533 multipliers -> n+ = 2^16
 
 
@@ -129,12 +153,17 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
     gens = g.BulletproofGens(ctx, 1 << (n - 1).bit_length(), 1)
     E = g.SonnyEdwardsPointGadget
 
+    ktimes = []
+
     def one(tag, verify):
         bl, ext_p, ext_v = randomness(tag)
         p = g.Prover(gens, b"ScalarMul")
         comms, vars_ = p.commit_batch_raw(vals, bl)
         E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
         proof = p.prove(gens, ext_p)
+        kt = p.kernel_timing()
+        if kt:
+            ktimes.append(kt)
         if verify:
             v = g.Verifier(b"ScalarMul")
             E.scalar_mul(E.from_point(base), v.commit_batch_raw(comms.raw), v).equal(E.from_point(expected), v)
@@ -201,7 +230,7 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
         secs.append(dt)
         cpu.append(dc)                                 # host CPU seconds of the whole process (all threads) in the timed pass
         cpu_sys.append(o1.system - o0.system)          # of which in the kernel (page faults, pinning, driver calls)
-    return threads * per_thread, secs, lat, first, (cpu, cpu_sys)
+    return threads * per_thread, secs, lat, first, (cpu, cpu_sys, ktimes)
 
 
 def proof_cpu_baseline(nbits=PROOF_BITS):
@@ -430,8 +459,9 @@ def main():
                   "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
                   "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0][0] / cnt, "prove_and_verify": 1e3 * cpu_s3[0][1] / cnt,
                                             "prove_kernel_mode": 1e3 * cpu_s3[1][0] / cnt,
-                                            "note": "process CPU time (all host threads; waits sleep on the device's interrupt unless BPG_SYNC=spin) "
+                                            "note": "process CPU time (all host threads; waits poll with 20-100 us naps unless BPG_SYNC=spin / block) "
                                                     "of this rank's timed pass / proofs; the box gives a rank 16 cores"},
+                  "scalar_kernels": scalar_kernel_report(cpu_s3[2]),
                   "workload": "Edwards scalar_mul gadget, %d committed bits (BASELINE configs[2]); independent proofs, "
                               "one per host thread, sharded across GPUs with no collective" % PROOF_BITS}
 

@@ -88,6 +88,7 @@ def lib():
         "bpg_prover_prove_many": (ci, [vp, sz, RNG_FN, vp, vp, sz, psz]),
         "bpg_prover_stats": (ci, [vp, psz, psz]),
         "bpg_prover_timing": (ci, [vp, dp]),
+        "bpg_prover_kernel_timing": (ci, [vp, dp, dp, dp]),
         "bpg_verifier_new": (ci, [cp, sz, pvp]),
         "bpg_verifier_free": (None, [vp]),
         "bpg_verifier_cs": (vp, [vp]),

@@ -202,15 +202,17 @@ void HostPhase::report() {
 //  * spinning (the runtime's default; BPG_SYNC=spin): 36.6 ms of thread CPU per proof at 16 threads.  Lowest latency for
 //    one proof alone, but a prover service runs more threads than cores and a spinning waiter takes a core from a
 //    thread that captures or draws.
-//  * the device's scheduling flag hipDeviceScheduleBlockingSync (bpg_init sets it when the device still takes it)
-//    makes the runtime sleep on an interrupt: 0.9 ms of CPU per proof inside the waits at 24 threads -- but every
-//    completed kernel wakes every sleeper: 10.4 ms at 48 threads.  (hipEventBlockingSync on an event alone still
-//    spins in user mode.)
-//  * polling the event with naps of 20-100 us: 0.7 ms at 48 threads, and about 8 % fewer proofs/s than the interrupt
-//    (the path is latency-bound under load, and a nap overshoots).
-// Default: the interrupt (most proofs/s: 416-453 at 48-64 threads against 371-398 polling), polling where the device's
-// flags are already fixed; BPG_SYNC=poll / spin force those.  A hybrid (interrupt for the first 12-36 simultaneous
-// waiters, polling beyond) was within the run-to-run noise of the plain interrupt in proofs/s and cost more CPU.
+//  * polling the event with naps of 20-100 us (the default; BPG_SYNC=poll): 0.7 ms of CPU per proof inside the waits at
+//    48 threads.  Every transfer of the hot paths goes through pinned staging (PinArena, h_raw, h_wit), so no wait
+//    hides inside the runtime where it would spin.
+//  * the device's scheduling flag hipDeviceScheduleBlockingSync (BPG_SYNC=block) makes the runtime sleep on an
+//    interrupt: 0.9 ms of CPU per proof inside the waits at 24 threads, 10.4 ms at 48 (every completed kernel wakes
+//    every sleeper), and 5-10 % more proofs/s than polling because a nap overshoots.  NOT the default: on ROCm 7.2 / this
+//    driver, once a process with the flag set has run a few thousand proofs from 16 threads, the first HIP call of any
+//    process started afterwards (hipGetDeviceCount in a child, while the parent lives) takes SIGSEGV inside the
+//    runtime's initialisation -- reproduced with the flag set and never without it.  A service that
+//    never starts another GPU process beside the prover may opt in.  (hipEventBlockingSync on an event alone still
+//    spins in user mode; a hybrid of interrupt and polling was within noise of the plain interrupt.)
 hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev) {
     if (!ctx->sync_block || !ctx->sync_poll) return hipEventSynchronize(ev);
     hipError_t e;
@@ -367,27 +369,28 @@ int bpg_init(int device_id, bpg_ctx **out) {
         }
     }
     BPG_CHECK_HIP(hipSetDevice(device_id));
-    // Host threads sleep in stream / event waits instead of spinning (many prover threads per GPU share the host
-    // cores with circuit capture and the transcript's Keccak chain); BPG_SYNC=spin restores the busy wait.
-    bool sync_block = true;
-    if (const char *s = getenv("BPG_SYNC")) sync_block = strcmp(s, "spin") != 0;
+    // Host threads nap in stream / event waits instead of spinning (many prover threads per GPU share the host cores
+    // with circuit capture and the transcript's Keccak chain).  BPG_SYNC = poll (default) | block | spin: see wait_event.
+    const char *mode = getenv("BPG_SYNC");
     bpg_ctx *ctx = new bpg_ctx();
-    ctx->sync_block = sync_block;
-    if (sync_block) {
-        // the device flag makes the waits INSIDE the runtime sleep too (pageable copies, allocation); it is refused once
-        // the device is in use with other flags, and the library's own waits then poll
-        const char *mode = getenv("BPG_SYNC");
+    ctx->device = device_id;
+    ctx->id = g_next_ctx_id.fetch_add(1);
+    ctx->sync_block = !(mode && !strcmp(mode, "spin"));
+    ctx->sync_poll = true;
+    if (mode && !strcmp(mode, "block")) {
+        // refused once the device is in use with other flags: the library's own waits then keep polling
         unsigned flags = 0;
         (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
         (void)hipGetLastError();
-        const bool took = hipGetDeviceFlags(&flags) == hipSuccess && (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync;
-        ctx->sync_poll = !took || (mode && !strcmp(mode, "poll"));
+        if (hipGetDeviceFlags(&flags) == hipSuccess && (flags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync)
+            ctx->sync_poll = false;
     }
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
             ctx->resident_lanes = cus * 4 * 4 * 64;
     }
+    if (const char *s = getenv("BPG_TIME_KERNELS")) ctx->time_kernels = atoi(s) != 0;
     if (const char *s = getenv("BPG_MSM_C")) ctx->tune.c = atoi(s);
     if (const char *s = getenv("BPG_MSM_TILE")) ctx->tune.tile = atoi(s);
     if (const char *s = getenv("BPG_MSM_LS0")) ctx->tune.ls0 = atoi(s);
@@ -427,9 +430,13 @@ void bpg_shutdown(bpg_ctx *ctx) {
         if (lane->d_io) (void)hipFree(lane->d_io);
         if (lane->h_raw) (void)hipHostFree(lane->h_raw);
         if (lane->h_wit) (void)hipHostFree(lane->h_wit);
+        if (lane->h_io) (void)hipHostFree(lane->h_io);
+        if (lane->h_ped) (void)hipHostFree(lane->h_ped);
         if (lane->d_vacc) (void)hipFree(lane->d_vacc);
         if (lane->d_vtail) (void)hipFree(lane->d_vtail);
         if (lane->ev_sync) (void)hipEventDestroy(lane->ev_sync);
+        for (auto &e : lane->ev_k)
+            if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(lane->stream);
         delete lane;
     }

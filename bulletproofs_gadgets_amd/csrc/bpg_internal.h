@@ -120,6 +120,7 @@ struct bpg_msm_job {
 struct bpg_lane {
     bpg_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;     // setup / codec / scalar-vector kernel stream
+    hipEvent_t ev_k[12] = {};         // start / stop events around the six scalar-vector kernels of a single proof (ctx->time_kernels)
     hipEvent_t ev_sync = nullptr;     // waits on `stream` go through this event (lane_sync); null when the context spins
     std::vector<bpg_msm_job *> jobs;  // MSM job pool (each job has its own stream)
     float last_acc_us = 0.f, last_total_us = 0.f;
@@ -144,6 +145,13 @@ struct bpg_lane {
     size_t h_raw_cap = 0;
     void *h_wit = nullptr;
     size_t h_wit_cap = 0;
+    // ... and every small transfer of a proof (challenge tables, blindings, partial sums, commitments) is staged here:
+    // a copy between pageable memory and the device makes the runtime wait inside the call, spinning unless the
+    // device's blocking-sync flag is set -- and that flag is not safe to set (api.hip: bpg_init)
+    void *h_io = nullptr;             // prove / verify (r1cs.hip: PinArena)
+    size_t h_io_cap = 0;
+    void *h_ped = nullptr;            // Pedersen batches
+    size_t h_ped_cap = 0;
     void *d_vacc = nullptr;
     size_t vacc_cap = 0;
     void *d_vtail = nullptr;
@@ -155,6 +163,7 @@ struct bpg_ctx {
     uint64_t id = 0;                  // process-unique; keys the per-thread lane cache
     bpg::msm_tuning tune;
     int resident_lanes = 262144;      // CUs x 4 SIMDs x 4 waves x 64 lanes: threads of k_accumulate resident at once
+    bool time_kernels = false;        // BPG_TIME_KERNELS=1: a single proof times its scalar-vector kernels (bpg_prover_kernel_timing)
     bool sync_block = true;           // waits sleep instead of spinning; BPG_SYNC=spin clears it
     bool sync_poll = false;           // waits always poll and nap (BPG_SYNC=poll, or the device's blocking-sync flag could not be set)
     std::mutex mu;                    // guards lanes, free_lanes

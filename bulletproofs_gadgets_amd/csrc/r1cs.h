@@ -292,7 +292,8 @@ struct ConstraintStore {
     // followed.  A circuit followed to its end is the cached circuit: prove / verify then take its resident
     // flattening plan without hashing or comparing 12 bytes per term again.
     std::shared_ptr<const CircuitKey> follow_key;
-    std::shared_ptr<void> follow_entry;          // the cache entry the key belongs to (r1cs.hip: FlatCached), if any
+    std::weak_ptr<void> follow_entry;            // the cache entry the key belongs to (r1cs.hip: FlatCached), if any.  Weak: the entry's
+                                                 // device memory belongs to its context's cache, not to whoever followed it
     size_t cur = 0;
     void follow(std::shared_ptr<const CircuitKey> key, std::shared_ptr<void> entry);   // only before anything is captured
     void materialize();
@@ -421,6 +422,11 @@ class Prover : public ConstraintSystem {
     size_t num_constraints() const { return cs_.num_constraints; }
     Transcript &transcript() { return tr_; }
     struct Timing { double rng_ms = 0, commit_ms = 0, poly_ms = 0, ipp_ms = 0, total_ms = 0; } timing;
+    // the scalar-vector kernels of the last single prove() under BPG_TIME_KERNELS=1 ("report GB/s for those"):
+    // k_zpow, k_flatten, k_poly, k_eval, k_ipp_rows and k_ipp_fold of round 0 -- dispatch time by HIP events, the bytes each
+    // has to move (inputs read once, outputs written once) and its multiplications mod l (Montgomery passes of 104 MAC)
+    static constexpr int N_TIMED = 6;
+    struct KernelTiming { double us[N_TIMED] = {}, bytes[N_TIMED] = {}, montmuls[N_TIMED] = {}; bool valid = false; } ktiming;
 
   private:
     // prove() in three steps: transcript RNG set-up, blinding draws (the host's long Keccak chain), the rest

@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <hip/hip_ext.h>
+
 #include "r1cs.h"
 
 namespace bpg {
@@ -37,6 +39,22 @@ __device__ __forceinline__ void st_sc(sc *p, const sc &v) {
 __device__ __forceinline__ sc mul_(const sc &a, const sc &b) { sc r; sc_mul(r, a, b); return r; }
 __device__ __forceinline__ sc add_(const sc &a, const sc &b) { sc r; sc_add(r, a, b); return r; }
 __device__ __forceinline__ sc sub_(const sc &a, const sc &b) { sc r; sc_sub(r, a, b); return r; }
+
+// Montgomery form (x R mod l, R = 2^256) is how these kernels halve their work: a plain product is two reductions
+// (sc_mul = montmul, montmul by R^2), but montmul(a, b R) = a b is one.  So per-kernel constants (challenges, their
+// powers) arrive as x R, power tables hold x^(2^k) R and a chain of products stays in that form, the inner-product
+// vectors a, b live in HBM as a R, b R, and sums of products are fixed once per block, not per term.
+__device__ __forceinline__ sc mm_(const sc &a, const sc &b) { sc r; sc_montmul(r, a, b); return r; }      // a b / R
+// x^e R from a table of x^(2^k) R, k < 32
+__device__ __forceinline__ sc pow_tbl_mont(const sc *tblR, uint32_t e) {
+    sc acc = sc_r();
+    for (int k = 0; e; k++, e >>= 1)
+        if (e & 1) acc = mm_(acc, ld_sc(tblR + k));
+    return acc;
+}
+// A thread of the strip kernels below owns elements i0, i0 + 256, .. (STRIP of them): one table walk for the first
+// power, one multiplication by x^256 (table entry 8) per further element, and the loads stay coalesced.
+constexpr int STRIP = 4;
 
 // x^e from a table of x^(2^k), k < 32
 __device__ __forceinline__ sc pow_tbl(const sc *tbl, uint32_t e) {
@@ -86,39 +104,48 @@ __device__ void block_sum(sc (&v)[NS], sc *out) {
 
 // =================================================================== kernels
 
-// zpow[q] = z^(q+1)
-__global__ void __launch_bounds__(256) k_zpow(const sc *__restrict__ ztbl, sc *__restrict__ zpow, uint32_t Q) {
-    uint32_t q = blockIdx.x * 256u + threadIdx.x;
-    if (q < Q) st_sc(zpow + q, pow_tbl(ztbl, q + 1));
+// zpowR[q] = z^(q+1) R (Montgomery form: the flattening multiplies it by plain coefficients).  ztblR[k] = z^(2^k) R.
+__global__ void __launch_bounds__(256) k_zpow(const sc *__restrict__ ztblR, sc *__restrict__ zpowR, uint32_t Q) {
+    uint32_t q = blockIdx.x * (256u * STRIP) + threadIdx.x;
+    if (q >= Q) return;
+    sc p = pow_tbl_mont(ztblR, q + 1);
+    const sc step = ld_sc(ztblR + 8);
+    st_sc(zpowR + q, p);
+#pragma unroll
+    for (int k = 1; k < STRIP; k++) {
+        q += 256u;
+        if (q >= Q) return;
+        p = mm_(p, step);
+        st_sc(zpowR + q, p);
+    }
 }
 
 // Flattened constraints: W[slot] = (+/-) sum over the slot's terms of z^(q+1) * coeff.
 // Slots: [0,n) wL, [n,2n) wR, [2n,3n) wO, [3n,3n+m) wV (negated), 3n+m: wc (negated).
 __global__ void __launch_bounds__(256) k_flatten(const uint32_t *__restrict__ slot_off, const uint32_t *__restrict__ t_coeff,
                                                  const uint32_t *__restrict__ t_q, const sc *__restrict__ coeffs,
-                                                 const sc *__restrict__ zpow, sc *__restrict__ W, uint32_t nslots,
+                                                 const sc *__restrict__ zpowR, sc *__restrict__ W, uint32_t nslots,
                                                  uint32_t neg_from) {
     uint32_t s = blockIdx.x * 256u + threadIdx.x;
     if (s >= nslots) return;
     sc acc = sc_zero();
-    for (uint32_t t = slot_off[s]; t < slot_off[s + 1]; t++) acc = add_(acc, mul_(ld_sc(zpow + t_q[t]), ld_sc(coeffs + t_coeff[t])));
+    for (uint32_t t = slot_off[s]; t < slot_off[s + 1]; t++) acc = add_(acc, mm_(ld_sc(zpowR + t_q[t]), ld_sc(coeffs + t_coeff[t])));
     if (s >= neg_from) sc_neg(acc, acc);
     st_sc(W + s, acc);
 }
 
 // per-block partial sums of  sum_t zpow[q_t] * coeffs[c_t]  (the constant terms -> wc)
 __global__ void __launch_bounds__(256) k_dot_zpow(const uint32_t *__restrict__ t_coeff, const uint32_t *__restrict__ t_q,
-                                                  const sc *__restrict__ coeffs, const sc *__restrict__ zpow, uint32_t nterms,
+                                                  const sc *__restrict__ coeffs, const sc *__restrict__ zpowR, uint32_t nterms,
                                                   sc *__restrict__ partial) {
     uint32_t t = blockIdx.x * 256u + threadIdx.x;
     sc v[1] = {sc_zero()};
-    if (t < nterms) v[0] = mul_(ld_sc(zpow + t_q[t]), ld_sc(coeffs + t_coeff[t]));
+    if (t < nterms) v[0] = mm_(ld_sc(zpowR + t_q[t]), ld_sc(coeffs + t_coeff[t]));
     block_sum<1>(v, partial);
 }
 
-// Provers that share their launches (finish_group): every kernel boundary costs the whole chip a cache write-back, and
-// under dozens of prover threads the hardware queues spend more time between kernels than in them, so the lever on
-// proofs/s is launches per proof.  The blinding RNG still advances eight states per permutation (two draws per group).
+// Provers that share their launches (finish_group): the latency-bound kernels around the accumulate pass then run once
+// per group, not once per proof.  The blinding RNG advances eight states per permutation (two draws per group of 16).
 constexpr size_t GROUP_MAX = 16;
 
 // l(X), r(X) coefficient vectors and the per-block partial sums of t1..t6
@@ -136,28 +163,41 @@ __global__ void __launch_bounds__(256) k_poly(uint32_t n, const poly_group G) {
     const sc *__restrict__ aL = P.aL, *__restrict__ aR = P.aR, *__restrict__ aO = P.aO, *__restrict__ sL = P.sL,
                           *__restrict__ sR = P.sR, *__restrict__ W = P.W, *__restrict__ ytbl = P.ytbl, *__restrict__ yinvtbl = P.yinvtbl;
     sc *__restrict__ l1 = P.l1, *__restrict__ r0 = P.r0, *__restrict__ r1 = P.r1, *__restrict__ r3 = P.r3, *__restrict__ partial = P.partial;
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    sc t[6];
+    uint32_t i = blockIdx.x * (256u * STRIP) + threadIdx.x;
+    sc t[6];                                   // sums of products a b / R: brought back to plain once, below
 #pragma unroll
     for (int k = 0; k < 6; k++) t[k] = sc_zero();
     if (i < n) {
-        sc yi = pow_tbl(ytbl, i), yinvi = pow_tbl(yinvtbl, i);
-        sc wL = ld_sc(W + i), wR = ld_sc(W + n + i), wO = ld_sc(W + 2 * (size_t)n + i);
-        sc vl1 = add_(ld_sc(aL + i), mul_(yinvi, wR));
-        sc vl2 = ld_sc(aO + i), vl3 = ld_sc(sL + i);
-        sc vr0 = sub_(wO, yi);
-        sc vr1 = add_(mul_(yi, ld_sc(aR + i)), wL);
-        sc vr3 = mul_(yi, ld_sc(sR + i));
-        st_sc(l1 + i, vl1);
-        st_sc(r0 + i, vr0);
-        st_sc(r1 + i, vr1);
-        st_sc(r3 + i, vr3);
-        t[0] = mul_(vl1, vr0);
-        t[1] = add_(mul_(vl1, vr1), mul_(vl2, vr0));
-        t[2] = add_(mul_(vl2, vr1), mul_(vl3, vr0));
-        t[3] = add_(mul_(vl1, vr3), mul_(vl3, vr1));
-        t[4] = mul_(vl2, vr3);
-        t[5] = mul_(vl3, vr3);
+        sc yiR = pow_tbl_mont(ytbl, i), yinviR = pow_tbl_mont(yinvtbl, i);        // ytbl / yinvtbl hold y^(+-2^k) R
+        const sc ystep = ld_sc(ytbl + 8), yinvstep = ld_sc(yinvtbl + 8), one = sc_one();
+#pragma unroll
+        for (int k = 0; k < STRIP; k++) {
+            if (k) {
+                i += 256u;
+                if (i >= n) break;
+                yiR = mm_(yiR, ystep);
+                yinviR = mm_(yinviR, yinvstep);
+            }
+            sc wL = ld_sc(W + i), wR = ld_sc(W + n + i), wO = ld_sc(W + 2 * (size_t)n + i);
+            sc vl1 = add_(ld_sc(aL + i), mm_(wR, yinviR));
+            sc vl2 = ld_sc(aO + i), vl3 = ld_sc(sL + i);
+            sc vr0 = sub_(wO, mm_(yiR, one));
+            sc vr1 = add_(mm_(ld_sc(aR + i), yiR), wL);
+            sc vr3 = mm_(ld_sc(sR + i), yiR);
+            st_sc(l1 + i, vl1);
+            st_sc(r0 + i, vr0);
+            st_sc(r1 + i, vr1);
+            st_sc(r3 + i, vr3);
+            t[0] = add_(t[0], mm_(vl1, vr0));
+            t[1] = add_(t[1], add_(mm_(vl1, vr1), mm_(vl2, vr0)));
+            t[2] = add_(t[2], add_(mm_(vl2, vr1), mm_(vl3, vr0)));
+            t[3] = add_(t[3], add_(mm_(vl1, vr3), mm_(vl3, vr1)));
+            t[4] = add_(t[4], mm_(vl2, vr3));
+            t[5] = add_(t[5], mm_(vl3, vr3));
+        }
+        const sc rr = sc_rr();
+#pragma unroll
+        for (int k = 0; k < 6; k++) t[k] = mm_(t[k], rr);
     }
     block_sum<6>(t, partial);
 }
@@ -166,37 +206,45 @@ __global__ void __launch_bounds__(256) k_poly(uint32_t n, const poly_group G) {
 //   sG_j = G_factors[j] = 1 (j < n) | u (pad)      sH_j = y^-j * G_factors[j]
 struct eval_proof {
     uint32_t n1;             // multipliers of the first phase: G_factors = 1 below n1, u from n1 on (second phase and padding)
-    sc x, u;
+    sc xR, xRR, x3RR, u;     // x R, x R^2, x^3 R^2 (Montgomery-form constants, see mm_), u plain
     const sc *l1, *aO, *sL, *r0, *r1, *r3, *ytbl, *yinvtbl;
-    sc *a, *b, *sG, *sH;
+    sc *a, *b, *sG, *sH;     // a, b are written as a R, b R (the round kernels keep them so); sG, sH plain
 };
 struct eval_group {
     eval_proof p[GROUP_MAX];
 };
 __global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, const eval_group G) {
     const eval_proof &P = G.p[blockIdx.y];
-    const sc x = P.x, u = P.u;
+    const sc xR = P.xR, xRR = P.xRR, x3RR = P.x3RR, u = P.u;
     const sc *__restrict__ l1 = P.l1, *__restrict__ aO = P.aO, *__restrict__ sL = P.sL, *__restrict__ r0 = P.r0, *__restrict__ r1 = P.r1,
                           *__restrict__ r3 = P.r3, *__restrict__ ytbl = P.ytbl, *__restrict__ yinvtbl = P.yinvtbl;
     sc *__restrict__ a = P.a, *__restrict__ b = P.b, *__restrict__ sG = P.sG, *__restrict__ sH = P.sH;
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t i = blockIdx.x * (256u * STRIP) + threadIdx.x;
     if (i >= np) return;
-    sc yinvi = pow_tbl(yinvtbl, i);
-    if (i < n) {
-        // l = x (l1 + x (l2 + x l3));  r = r0 + x (r1 + x (x r3))
-        sc l = mul_(x, add_(ld_sc(l1 + i), mul_(x, add_(ld_sc(aO + i), mul_(x, ld_sc(sL + i))))));
-        sc r = add_(ld_sc(r0 + i), mul_(x, add_(ld_sc(r1 + i), mul_(x, mul_(x, ld_sc(r3 + i))))));
-        st_sc(a + i, l);
-        st_sc(b + i, r);
-        st_sc(sG + i, i < P.n1 ? sc_one() : u);
-        st_sc(sH + i, i < P.n1 ? yinvi : mul_(yinvi, u));
-    } else {
-        sc yi = pow_tbl(ytbl, i), neg;
-        sc_neg(neg, yi);
-        st_sc(a + i, sc_zero());
-        st_sc(b + i, neg);
-        st_sc(sG + i, u);
-        st_sc(sH + i, mul_(yinvi, u));
+    sc yinviR = pow_tbl_mont(yinvtbl, i);
+    const sc yinvstep = ld_sc(yinvtbl + 8), one = sc_one(), rr = sc_rr();
+#pragma unroll
+    for (int k = 0; k < STRIP; k++) {
+        if (k) {
+            i += 256u;
+            if (i >= np) return;
+            yinviR = mm_(yinviR, yinvstep);
+        }
+        const bool first = i < P.n1;
+        st_sc(sG + i, first ? one : u);
+        st_sc(sH + i, mm_(yinviR, first ? one : u));              // y^-i (u): plain
+        if (i < n) {
+            // l = x (l1 + x (l2 + x l3));  r = r0 + x r1 + x^3 r3; both leave as (.) R
+            sc l = mm_(add_(ld_sc(l1 + i), mm_(add_(ld_sc(aO + i), mm_(ld_sc(sL + i), xR)), xR)), xRR);
+            sc r = add_(mm_(ld_sc(r0 + i), rr), add_(mm_(ld_sc(r1 + i), xRR), mm_(ld_sc(r3 + i), x3RR)));
+            st_sc(a + i, l);
+            st_sc(b + i, r);
+        } else {
+            sc negR;
+            sc_neg(negR, pow_tbl_mont(ytbl, i));                  // padding: a = 0, b = -y^i
+            st_sc(a + i, sc_zero());
+            st_sc(b + i, negR);
+        }
     }
 }
 
@@ -208,11 +256,11 @@ __global__ void __launch_bounds__(256) k_eval(uint32_t n, uint32_t np, const eva
 // The three round kernels serve a group of up to 8 proofs per launch (blockIdx.y = proof): alone they are
 // launch-bound (17 us for 2048 elements), and a group's rounds are in lock-step anyway.
 struct ipp_proof {
-    sc *a, *b, *sG, *sH;       // the proof's vectors
-    sc *rowL, *rowR;           // its block of the L / R scalar rows
-    sc *cpart;                 // per-block partial sums of (c_L, c_R)
+    sc *a, *b, *sG, *sH;       // the proof's vectors: a, b in Montgomery form (a R, b R), sG, sH plain
+    sc *rowL, *rowR;           // its block of the L / R scalar rows (plain: the MSM reads them)
+    sc *cpart;                 // per-block partial sums of (c_L R, c_R R)
     sc *outL, *outR;           // where the rows keep the scalar of B
-    sc w, u, uinv;             // Q = w B; the round's challenge and its inverse
+    sc w, uR, uinvR;           // Q = w B (plain); the round's challenge and its inverse, times R
 };
 struct ipp_group {
     ipp_proof p[GROUP_MAX];
@@ -227,16 +275,16 @@ __global__ void __launch_bounds__(256) k_ipp_rows(uint32_t np, uint32_t nk, cons
         const uint32_t half = nk >> 1, idx = j & (nk - 1);
         const bool hi = idx >= half;
         const uint32_t other = hi ? idx - half : idx + half;
-        sc ga = mul_(ld_sc(a + other), ld_sc(sG + j));
-        sc hb = mul_(ld_sc(b + other), ld_sc(sH + j));
+        sc ga = mm_(ld_sc(a + other), ld_sc(sG + j));             // (a R) sG / R = a sG
+        sc hb = mm_(ld_sc(b + other), ld_sc(sH + j));
         const sc zero = sc_zero();
         st_sc(rowL + j, hi ? ga : zero);
         st_sc(rowR + j, hi ? zero : ga);
         st_sc(rowL + np + j, hi ? zero : hb);
         st_sc(rowR + np + j, hi ? hb : zero);
         if (j < half) {
-            c[0] = mul_(ld_sc(a + j), ld_sc(b + half + j));
-            c[1] = mul_(ld_sc(a + half + j), ld_sc(b + j));
+            c[0] = mm_(ld_sc(a + j), ld_sc(b + half + j));        // (a R)(b R) / R = a b R
+            c[1] = mm_(ld_sc(a + half + j), ld_sc(b + j));
         }
     }
     block_sum<2>(c, partial);
@@ -257,8 +305,8 @@ __global__ void __launch_bounds__(256) k_ipp_c(uint32_t nblocks, const ipp_group
     block_sum<2>(c, res);
     __syncthreads();
     if (threadIdx.x == 0) {
-        st_sc(outL, mul_(res[0], w));
-        st_sc(outR, mul_(res[1], w));
+        st_sc(outL, mm_(res[0], w));                              // (c R) w / R = c w
+        st_sc(outR, mm_(res[1], w));
     }
 }
 
@@ -266,16 +314,16 @@ __global__ void __launch_bounds__(256) k_ipp_c(uint32_t nblocks, const ipp_group
 __global__ void __launch_bounds__(256) k_ipp_fold(uint32_t np, uint32_t nk, const ipp_group G) {
     const ipp_proof &P = G.p[blockIdx.y];
     sc *__restrict__ a = P.a, *__restrict__ b = P.b, *__restrict__ sG = P.sG, *__restrict__ sH = P.sH;
-    const sc u = P.u, uinv = P.uinv;
+    const sc uR = P.uR, uinvR = P.uinvR;
     uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= np) return;
     const uint32_t half = nk >> 1, idx = j & (nk - 1);
     const bool hi = idx >= half;
-    st_sc(sG + j, mul_(ld_sc(sG + j), hi ? u : uinv));
-    st_sc(sH + j, mul_(ld_sc(sH + j), hi ? uinv : u));
+    st_sc(sG + j, mm_(ld_sc(sG + j), hi ? uR : uinvR));
+    st_sc(sH + j, mm_(ld_sc(sH + j), hi ? uinvR : uR));
     if (j < half) {
-        sc na = add_(mul_(ld_sc(a + j), u), mul_(uinv, ld_sc(a + half + j)));
-        sc nb = add_(mul_(ld_sc(b + j), uinv), mul_(u, ld_sc(b + half + j)));
+        sc na = add_(mm_(ld_sc(a + j), uR), mm_(ld_sc(a + half + j), uinvR));
+        sc nb = add_(mm_(ld_sc(b + j), uinvR), mm_(ld_sc(b + half + j), uR));
         st_sc(a + j, na);
         st_sc(b + j, nb);
     }
@@ -693,12 +741,65 @@ struct Arena {
 };
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// Pinned staging for the small transfers of one prove / verify call (lane->h_io): a bump allocator that the call sizes up
+// front.  h2d copies the source in and enqueues a plain DMA; d2h enqueues the DMA into the staging and remembers where the
+// bytes belong, collect() -- after the caller's next wait on the stream -- delivers them.  Where the staging cannot be had
+// (allocation failure, a call that outgrows its estimate) the transfer falls back to the pageable pointer.
+struct PinArena {
+    bpg_lane *lane;
+    size_t used = 0;
+    struct Pending {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
+    std::vector<Pending> pending;
+    explicit PinArena(bpg_lane *l) : lane(l) {}
+    void reserve(size_t bytes) { (void)grow_pinned(&lane->h_io, &lane->h_io_cap, bytes); }
+    void *take(size_t bytes) {
+        const size_t b = (bytes + 63) & ~(size_t)63;
+        if (!lane->h_io || used + b > lane->h_io_cap) return nullptr;
+        void *p = (uint8_t *)lane->h_io + used;
+        used += b;
+        return p;
+    }
+    hipError_t h2d(void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
+        if (void *st = take(bytes)) {
+            memcpy(st, h_src, bytes);
+            h_src = st;
+        }
+        return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s);
+    }
+    hipError_t d2h(void *h_dst, const void *d_src, size_t bytes, hipStream_t s) {
+        if (void *st = take(bytes)) {
+            pending.push_back({h_dst, st, bytes});
+            h_dst = st;
+        }
+        return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s);
+    }
+    void collect() {                       // after a wait on the stream
+        for (auto &p : pending) memcpy(p.dst, p.src, p.bytes);
+        pending.clear();
+    }
+};
+
 static void pow2_table(sc out[32], const sc &x) {
     out[0] = x;
     for (int k = 1; k < 32; k++) sc_mul(out[k], out[k - 1], out[k - 1]);
 }
 
 static unsigned grid256(size_t n) { return (unsigned)((n + 255) / 256); }
+static unsigned grid_strip(size_t n) { return (unsigned)((n + 256 * STRIP - 1) / (256 * STRIP)); }      // the strip kernels: STRIP elements per thread
+// x^(2^k) R, k < 32: the form the strip kernels take their power tables in (pow_tbl_mont)
+static void pow2_table_mont(sc out[32], const sc &x) {
+    pow2_table(out, x);
+    for (int k = 0; k < 32; k++) sc_to_mont(out[k], out[k]);
+}
+static sc to_mont(const Scalar &x) {
+    sc r;
+    sc_to_mont(r, x.v);
+    return r;
+}
 
 static double now_ms() {
     using namespace std::chrono;
@@ -802,8 +903,10 @@ static uint64_t hash_words(const std::vector<uint32_t> &v, uint64_t h) {
 
 // The circuit each side flattened last in this process: what the next Prover (role 0) / Verifier (role 1) follows
 // while it captures (ConstraintStore::follow).  A wrong guess costs one early mismatch.
+// (Weak references: the entries' device memory belongs to their context's cache and goes at bpg_shutdown; a strong
+// reference here would free it from a static destructor, after the HIP runtime has gone.)
 static std::mutex g_last_mu;
-static std::shared_ptr<FlatCached> g_last_shape[2];
+static std::weak_ptr<FlatCached> g_last_shape[2];
 
 static void remember_shape(const std::shared_ptr<FlatCached> &e) {
     std::lock_guard<std::mutex> lk(g_last_mu);
@@ -811,20 +914,21 @@ static void remember_shape(const std::shared_ptr<FlatCached> &e) {
 }
 static std::shared_ptr<FlatCached> last_shape(int role) {
     std::lock_guard<std::mutex> lk(g_last_mu);
-    return g_last_shape[role];
+    return g_last_shape[role].lock();
 }
 void forget_shapes_of(uint64_t ctx_id) {                    // bpg_shutdown: the entries' device memory goes with the context
     std::lock_guard<std::mutex> lk(g_last_mu);
-    for (auto &e : g_last_shape)
-        if (e && e->ctx_id == ctx_id) e.reset();
+    for (auto &w : g_last_shape)
+        if (auto e = w.lock())
+            if (e->ctx_id == ctx_id) w.reset();
 }
 
 static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, ConstraintStore &cs, uint32_t n, uint32_t m, bool want_wc,
                             std::shared_ptr<FlatCached> &out) {
     // a capture that followed a cached circuit to its end IS that circuit (every term was compared on the way)
-    if (cs.followed_fully() && cs.follow_entry) {
-        auto e = std::static_pointer_cast<FlatCached>(cs.follow_entry);
-        if (e->ctx_id == ctx->id && e->n == n && e->m == m && e->want_wc == want_wc) {
+    if (cs.followed_fully()) {
+        auto e = std::static_pointer_cast<FlatCached>(cs.follow_entry.lock());
+        if (e && e->ctx_id == ctx->id && e->n == n && e->m == m && e->want_wc == want_wc) {
             ctx->flat_hits++;
             ctx->flat_followed++;
             out = e;
@@ -900,21 +1004,20 @@ static int flat_plan_cached(bpg_ctx *ctx, bpg_lane *lane, ConstraintStore &cs, u
 // runs k_zpow + k_flatten (+ k_dot_zpow for the constant terms); W (device) receives
 // nslots scalars; *d_one / *n_one receive the per-block partial sums of sum z^(q+1) c over
 // the constant terms (the caller adds them up and negates to get wc).
-static int gpu_flatten(bpg_lane *lane, Arena &ar, const ConstraintStore &cs, const FlatCached &fc, const sc &z, sc *d_W,
-                       sc **d_one = nullptr, size_t *n_one = nullptr) {
+static int gpu_flatten(bpg_lane *lane, Arena &ar, PinArena &pin, const ConstraintStore &cs, const FlatCached &fc, const sc &z, sc *d_W,
+                       sc **d_one = nullptr, size_t *n_one = nullptr, hipEvent_t *ev = nullptr /* 4: zpow, flatten start / stop */) {
     hipStream_t s = lane->stream;
     const FlatPlan &fp = fc.fp;
     const uint32_t Q = cs.num_constraints;
     sc ztbl[32];
-    pow2_table(ztbl, z);
+    pow2_table_mont(ztbl, z);
     sc *d_ztbl = ar.take<sc>(32), *d_zpow = ar.take<sc>(Q ? Q : 1), *d_coeffs = ar.take<sc>(cs.coeffs.size() ? cs.coeffs.size() : 1);
-    BPG_CHECK_HIP(hipMemcpyAsync(d_ztbl, ztbl, sizeof ztbl, hipMemcpyHostToDevice, s));
-    if (!cs.coeffs.empty())
-        BPG_CHECK_HIP(hipMemcpyAsync(d_coeffs, cs.coeffs.data(), cs.coeffs.size() * sizeof(sc), hipMemcpyHostToDevice, s));
-    if (Q) hipLaunchKernelGGL(k_zpow, dim3(grid256(Q)), dim3(256), 0, s, d_ztbl, d_zpow, Q);
+    BPG_CHECK_HIP(pin.h2d(d_ztbl, ztbl, sizeof ztbl, s));
+    if (!cs.coeffs.empty()) BPG_CHECK_HIP(pin.h2d(d_coeffs, cs.coeffs.data(), cs.coeffs.size() * sizeof(sc), s));
+    if (Q) hipExtLaunchKernelGGL(k_zpow, dim3(grid_strip(Q)), dim3(256), 0, s, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0, d_ztbl, d_zpow, Q);
     if (fp.nslots)
-        hipLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, fc.d_off, fc.d_tc, fc.d_tq, d_coeffs, d_zpow, d_W,
-                           fp.nslots, fp.neg_from);
+        hipExtLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, 0, fc.d_off,
+                              fc.d_tc, fc.d_tq, d_coeffs, d_zpow, d_W, fp.nslots, fp.neg_from);
     if (d_one) {
         const size_t no = fp.nones, nb = grid256(no ? no : 1);
         *n_one = no ? nb : 0;
@@ -1024,11 +1127,19 @@ static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     if ((rc = grow(&lane->d_io, &lane->io_cap, m * 96))) return rc;
     sc *d_s = (sc *)lane->d_io;
     uint8_t *d_o = (uint8_t *)lane->d_io + m * 64;
-    BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
+    // both directions through pinned staging of the lane's own (plain DMAs: no wait inside the runtime)
+    uint8_t *h_in = nullptr, *h_out = nullptr;
+    if (grow_pinned(&lane->h_ped, &lane->h_ped_cap, m * 96) == BPG_OK) {
+        h_in = (uint8_t *)lane->h_ped;
+        h_out = h_in + m * 64;
+        memcpy(h_in, vr, m * 64);
+    }
+    BPG_CHECK_HIP(hipMemcpyAsync(d_s, h_in ? (const void *)h_in : (const void *)vr, m * 64, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(hipMemcpyAsync(h_out ? h_out : out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(lane_sync(lane));
+    if (h_out) memcpy(out32, h_out, m * 32);
     return BPG_OK;
 }
 
@@ -1507,6 +1618,14 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     }
     const bool two_phase = ps[0]->two_phase_done_;
     const size_t n = ps[0]->a_L_.size();
+    // BPG_TIME_KERNELS=1: a proof alone times its scalar-vector kernels (start / stop events on the dispatches)
+    hipEvent_t *evk = nullptr;
+    ps[0]->ktiming.valid = false;
+    if (ctx->time_kernels && g == 1 && n) {
+        evk = lane->ev_k;
+        for (auto &e : lane->ev_k)
+            if (!e) BPG_CHECK_HIP(hipEventCreate(&e));
+    }
     for (size_t j = 1; j < g; j++)
         if (ps[j]->a_L_.size() != n || ps[j]->gens_ != gens) return BPG_EINVAL;
     const size_t np = next_pow2(n ? n : 1);
@@ -1516,7 +1635,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
     // ---- device workspace
     const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
-    const size_t nblk_n = grid256(n ? n : 1), nblk_np = grid256(np);
+    const size_t nblk_n = grid_strip(n ? n : 1), nblk_np = grid256(np);
     // materialize the folded generators after round k0 (see msm_fold_submit): later rounds run on 2m points per proof
     int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg) : ctx->tune.ipp_fold;
     if (gens->world != 1 || k0 < 1 || (size_t)k0 >= lg || (np >> k0) < 32) k0 = 0;
@@ -1543,6 +1662,13 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     Arena ar(lane);
     int rc = ar.reserve(need);
     if (rc) return rc;
+    PinArena pin(lane);
+    {
+        size_t pneed = 1 << 16;
+        for (size_t j = 0; j < g; j++)
+            pneed += 4096 + 3 * 1024 + (ps[j]->cs_.coeffs.size() + 1) * 32 + nblk_n * 6 * 32 + (ps[j]->v_.size() + 1) * 32 + 64 * 8;
+        pin.reserve(pneed);
+    }
     std::unique_ptr<HostPhase> hp_up(new HostPhase(HostPhase::UPLOAD));
     sc *d_rows_all = ar.take<sc>(g * 3 * N1);             // proof j: rows 3j .. 3j+2
     sc *d_rowLR_all = ar.take<sc>(row_words);             // proof j: rows 2j, 2j+1
@@ -1569,9 +1695,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.d_aO = f.d_rows + N1 + 1;                         // row 1 = [o_bl | a_O | 0]
         f.d_sL = f.d_rows + 2 * N1 + 1;                     // row 2 = [s_bl | s_L | s_R]
         f.d_sR = f.d_rows + 2 * N1 + 1 + n;
-        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows, &p.i_bl_, 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + N1, &p.o_bl_, 32, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(f.d_rows + 2 * N1, &p.s_bl_, 32, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(pin.h2d(f.d_rows, &p.i_bl_, 32, s));
+        BPG_CHECK_HIP(pin.h2d(f.d_rows + N1, &p.o_bl_, 32, s));
+        BPG_CHECK_HIP(pin.h2d(f.d_rows + 2 * N1, &p.s_bl_, 32, s));
         if (n) {
             const sc *hL = p.a_L_.data(), *hR = p.a_R_.data(), *hO = p.a_O_.data();
             if (h_wit) {
@@ -1646,14 +1772,14 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.y = p.tr_.challenge_scalar("y");
         f.z = p.tr_.challenge_scalar("z");
         f.d_W = ar.take<sc>(f.fc->fp.nslots + 1);
-        if ((rc = gpu_flatten(lane, ar, p.cs_, *f.fc, f.z.v, f.d_W))) return rc;
+        if ((rc = gpu_flatten(lane, ar, pin, p.cs_, *f.fc, f.z.v, f.d_W, nullptr, nullptr, evk))) return rc;
         const Scalar y_inv = f.y.invert();
-        pow2_table(f.ytbl, f.y.v);
-        pow2_table(f.yinvtbl, y_inv.v);
+        pow2_table_mont(f.ytbl, f.y.v);
+        pow2_table_mont(f.yinvtbl, y_inv.v);
         f.d_ytbl = ar.take<sc>(32);
         f.d_yinvtbl = ar.take<sc>(32);
-        BPG_CHECK_HIP(hipMemcpyAsync(f.d_ytbl, f.ytbl, sizeof f.ytbl, hipMemcpyHostToDevice, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(f.d_yinvtbl, f.yinvtbl, sizeof f.yinvtbl, hipMemcpyHostToDevice, s));
+        BPG_CHECK_HIP(pin.h2d(f.d_ytbl, f.ytbl, sizeof f.ytbl, s));
+        BPG_CHECK_HIP(pin.h2d(f.d_yinvtbl, f.yinvtbl, sizeof f.yinvtbl, s));
         f.d_l1 = ar.take<sc>(n + 1);
         f.d_r0 = ar.take<sc>(n + 1);
         f.d_r1 = ar.take<sc>(n + 1);
@@ -1664,16 +1790,18 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         pgrp.p[j] = poly_proof{f.d_aL, f.d_aR, f.d_aO, f.d_sL, f.d_sR, f.d_W, f.d_ytbl, f.d_yinvtbl, f.d_l1, f.d_r0, f.d_r1, f.d_r3, f.d_part};
     }
     if (n) {
-        hipLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n, (unsigned)g), dim3(256), 0, s, (uint32_t)n, pgrp);
+        hipExtLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n, (unsigned)g), dim3(256), 0, s, evk ? evk[4] : nullptr, evk ? evk[5] : nullptr, 0,
+                              (uint32_t)n, pgrp);
         BPG_CHECK_HIP(hipGetLastError());
     }
     for (size_t j = 0; j < g; j++) {
         PF &f = pf[j];
         const size_t m = ps[j]->v_.size();
-        if (n) BPG_CHECK_HIP(hipMemcpyAsync(f.h_part.data(), f.d_part, nblk_n * 6 * 32, hipMemcpyDeviceToHost, s));
-        if (m) BPG_CHECK_HIP(hipMemcpyAsync(f.wV.data(), f.d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
+        if (n) BPG_CHECK_HIP(pin.d2h(f.h_part.data(), f.d_part, nblk_n * 6 * 32, s));
+        if (m) BPG_CHECK_HIP(pin.d2h(f.wV.data(), f.d_W + 3 * n, m * 32, s));
     }
     BPG_CHECK_HIP(lane_sync(lane));
+    pin.collect();
 
     hp_poly.reset();
     // ---- T_1, T_3..T_6 of every proof: one batch of 5g Pedersen commitments
@@ -1732,12 +1860,17 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.d_sH = f.d_sG + np;
         f.d_cpart = ar.take<sc>(nblk_np * 2);
         f.d_rowLR = d_rowLR_all + j * 2 * NR;
-        egrp.p[j] = eval_proof{(uint32_t)p.n1_, f.x.v, f.u.v, f.d_l1, f.d_aO, f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl, f.d_a, f.d_b, f.d_sG, f.d_sH};
+        {
+            const sc xR = to_mont(f.x), xRR = to_mont(Scalar(xR)), x3RR = to_mont(Scalar(to_mont(f.x * f.x * f.x)));
+            egrp.p[j] = eval_proof{(uint32_t)p.n1_, xR, xRR, x3RR, f.u.v, f.d_l1, f.d_aO, f.d_sL, f.d_r0, f.d_r1, f.d_r3, f.d_ytbl, f.d_yinvtbl,
+                                   f.d_a, f.d_b, f.d_sG, f.d_sH};
+        }
         p.tr_.innerproduct_domain_sep(np);
         P.L_vec.assign(32 * lg, 0);
         P.R_vec.assign(32 * lg, 0);
     }
-    hipLaunchKernelGGL(k_eval, dim3((unsigned)nblk_np, (unsigned)g), dim3(256), 0, s, (uint32_t)n, (uint32_t)np, egrp);
+    hipExtLaunchKernelGGL(k_eval, dim3(grid_strip(np), (unsigned)g), dim3(256), 0, s, evk ? evk[6] : nullptr, evk ? evk[7] : nullptr, 0,
+                          (uint32_t)n, (uint32_t)np, egrp);
     BPG_CHECK_HIP(hipGetLastError());
     const double poly_ms = (now_ms() - t2) / (double)g;
 
@@ -1784,7 +1917,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             q.outL = row0 + boff; q.outR = row0 + cstride + boff;
             q.w = f.w.v;
         }
-        hipLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, grp);
+        const bool tk = evk && k == 0;
+        hipExtLaunchKernelGGL(k_ipp_rows, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, tk ? evk[8] : nullptr, tk ? evk[9] : nullptr, 0,
+                              (uint32_t)cnp, (uint32_t)nk, grp);
         hipLaunchKernelGGL(k_ipp_c, dim3(1, (unsigned)g), dim3(256), 0, s, (uint32_t)cblk, grp);
         BPG_CHECK_HIP(hipGetLastError());
         BPG_CHECK_HIP(lane_sync(lane));
@@ -1820,21 +1955,41 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             p.tr_.append_point("L", o);
             p.tr_.append_point("R", o + 32);
             const Scalar uk = p.tr_.challenge_scalar("u"), uk_inv = uk.invert();
-            grp.p[j].u = uk.v;
-            grp.p[j].uinv = uk_inv.v;
+            grp.p[j].uR = to_mont(uk);
+            grp.p[j].uinvR = to_mont(uk_inv);
         }
-        hipLaunchKernelGGL(k_ipp_fold, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, (uint32_t)cnp, (uint32_t)nk, grp);
+        hipExtLaunchKernelGGL(k_ipp_fold, dim3((unsigned)cblk, (unsigned)g), dim3(256), 0, s, tk ? evk[10] : nullptr, tk ? evk[11] : nullptr, 0,
+                              (uint32_t)cnp, (uint32_t)nk, grp);
         BPG_CHECK_HIP(hipGetLastError());
     }
     std::vector<sc> hab(2 * g);
     for (size_t j = 0; j < g; j++) {
-        BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j], pf[j].d_a, 32, hipMemcpyDeviceToHost, s));
-        BPG_CHECK_HIP(hipMemcpyAsync(&hab[2 * j + 1], pf[j].d_b, 32, hipMemcpyDeviceToHost, s));
+        BPG_CHECK_HIP(pin.d2h(&hab[2 * j], pf[j].d_a, 32, s));
+        BPG_CHECK_HIP(pin.d2h(&hab[2 * j + 1], pf[j].d_b, 32, s));
     }
     BPG_CHECK_HIP(lane_sync(lane));
+    pin.collect();
     const double ipp_ms = (now_ms() - t3) / (double)g, t_end = now_ms();
+    if (evk && lg >= 1) {
+        Prover &p = *ps[0];
+        const FlatPlan &fp = pf[0].fc->fp;
+        const double Q = p.cs_.num_constraints, nt = (double)fp.nterms, ns = fp.nslots, dn = (double)n, dnp = (double)np;
+        // bytes every kernel has to move (32-byte scalars) and its Montgomery multiplications
+        const double bytes[N_TIMED] = {32 * Q, 40 * nt + 36 * ns, 384 * dn, 192 * dn + 128 * dnp, 320 * dnp, 224 * dnp};
+        const double mm[N_TIMED] = {Q * (1 + 8.0 / STRIP), nt, dn * (15 + (6 + 16.0) / STRIP), dn * 6 + dnp * (2 + 8.0 / STRIP), 3 * dnp, 4 * dnp};
+        for (int i = 0; i < N_TIMED; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, evk[2 * i], evk[2 * i + 1]);
+            p.ktiming.us[i] = ms * 1e3;
+            p.ktiming.bytes[i] = bytes[i];
+            p.ktiming.montmuls[i] = mm[i];
+        }
+        p.ktiming.valid = true;
+    }
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
+        sc_from_mont(hab[2 * j], hab[2 * j]);                 // the vectors live as a R, b R on the device
+        sc_from_mont(hab[2 * j + 1], hab[2 * j + 1]);
         out[j].a = Scalar(hab[2 * j]);
         out[j].b = Scalar(hab[2 * j + 1]);
         p.timing.poly_ms = poly_ms;
@@ -1970,24 +2125,27 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     sc *d_W = ar.take<sc>(fp.nslots + 1);
     sc *d_one = nullptr;
     size_t n_one = 0;
-    if ((rc = gpu_flatten(lane, ar, cs_, *fc, z.v, d_W, &d_one, &n_one))) return rc;
+    PinArena pin(lane);
+    pin.reserve((1 << 16) + (cs_.coeffs.size() + 1) * 32 + 3 * 1024 + 2 * (lg + 1) * 32 + (nblk + m + 2) * 32 + (fp.nones / 256 + 2) * 32);
+    if ((rc = gpu_flatten(lane, ar, pin, cs_, *fc, z.v, d_W, &d_one, &n_one))) return rc;
     sc yinvtbl[32];
     pow2_table(yinvtbl, y.invert().v);
     sc *d_yinvtbl = ar.take<sc>(32), *d_uk = ar.take<sc>(lg + 1), *d_ukinv = ar.take<sc>(lg + 1);
     sc *d_sc = ar.take<sc>(NS), *d_part = ar.take<sc>(nblk);
-    BPG_CHECK_HIP(hipMemcpyAsync(d_yinvtbl, yinvtbl, sizeof yinvtbl, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_uk, uk.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
-    BPG_CHECK_HIP(hipMemcpyAsync(d_ukinv, ukinv.data(), (lg + 1) * 32, hipMemcpyHostToDevice, s));
+    BPG_CHECK_HIP(pin.h2d(d_yinvtbl, yinvtbl, sizeof yinvtbl, s));
+    BPG_CHECK_HIP(pin.h2d(d_uk, uk.data(), (lg + 1) * 32, s));
+    BPG_CHECK_HIP(pin.h2d(d_ukinv, ukinv.data(), (lg + 1) * 32, s));
     verify_args A{x.v, P.a.v, P.b.v, u.v, (uint32_t)n, (uint32_t)np, (uint32_t)lg, (uint32_t)n1};
     // scalar row order = table order: [ g (G) | h (H) | B | B~ | dyn ]
     hipLaunchKernelGGL(k_verify_scalars, dim3((unsigned)nblk), dim3(256), 0, s, A, d_W, d_yinvtbl, d_uk, d_ukinv, d_sc, d_sc + np,
                        d_part);
     BPG_CHECK_HIP(hipGetLastError());
     std::vector<sc> h_part(nblk), wV(m + 1), h_one(n_one + 1);
-    BPG_CHECK_HIP(hipMemcpyAsync(h_part.data(), d_part, nblk * 32, hipMemcpyDeviceToHost, s));
-    if (m) BPG_CHECK_HIP(hipMemcpyAsync(wV.data(), d_W + 3 * n, m * 32, hipMemcpyDeviceToHost, s));
-    if (n_one) BPG_CHECK_HIP(hipMemcpyAsync(h_one.data(), d_one, n_one * 32, hipMemcpyDeviceToHost, s));
+    BPG_CHECK_HIP(pin.d2h(h_part.data(), d_part, nblk * 32, s));
+    if (m) BPG_CHECK_HIP(pin.d2h(wV.data(), d_W + 3 * n, m * 32, s));
+    if (n_one) BPG_CHECK_HIP(pin.d2h(h_one.data(), d_one, n_one * 32, s));
     BPG_CHECK_HIP(lane_sync(lane));
+    pin.collect();
     Scalar delta(0), wc(0);
     for (size_t b = 0; b < nblk; b++) delta += Scalar(h_part[b]);
     for (size_t b = 0; b < n_one; b++) wc -= Scalar(h_one[b]);

@@ -214,6 +214,18 @@ int bpg_prover_timing(const bpg_prover *p, double out_ms[5]) {
     return BPG_OK;
 }
 
+int bpg_prover_kernel_timing(const bpg_prover *p, double out_us[6], double out_bytes[6], double out_montmuls[6]) {
+    if (!p || !out_us || !out_bytes || !out_montmuls) return BPG_EINVAL;
+    const auto &k = p->p->ktiming;
+    if (!k.valid) return BPG_EINVAL;
+    for (int i = 0; i < Prover::N_TIMED; i++) {
+        out_us[i] = k.us[i];
+        out_bytes[i] = k.bytes[i];
+        out_montmuls[i] = k.montmuls[i];
+    }
+    return BPG_OK;
+}
+
 // ---------------------------------------------------------------- verifier
 int bpg_verifier_new(const uint8_t *label, size_t label_len, bpg_verifier **out) {
     if (!out) return BPG_EINVAL;

@@ -311,6 +311,16 @@ class Prover(_CS):
         check(lib().bpg_prover_timing(self._h, t))
         return dict(zip(("rng_ms", "commit_ms", "poly_ms", "ipp_ms", "total_ms"), t))
 
+    KERNELS = ("k_zpow", "k_flatten", "k_poly", "k_eval", "k_ipp_rows", "k_ipp_fold")
+
+    def kernel_timing(self):
+        """{kernel: (microseconds, bytes to move, multiplications mod l)} of the last single prove() when the context was
+        created with BPG_TIME_KERNELS=1 in the environment; None otherwise (bpg_prover_kernel_timing)"""
+        us, by, mm = (ctypes.c_double * 6)(), (ctypes.c_double * 6)(), (ctypes.c_double * 6)()
+        if lib().bpg_prover_kernel_timing(self._h, us, by, mm) != _native.OK:
+            return None
+        return {k: (us[i], by[i], mm[i]) for i, k in enumerate(self.KERNELS)}
+
     def __del__(self):
         try:
             if self._h:

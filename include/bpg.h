@@ -203,6 +203,13 @@ int bpg_prover_stats(const bpg_prover *p, size_t *multipliers, size_t *constrain
 /* milliseconds of the last prove(): blinding RNG, A/S commitments, polynomial phase, inner-product argument, total */
 int bpg_prover_timing(const bpg_prover *p, double out_ms[5]);
 
+/* Diagnostics for bench.py (HBM GB/s of the scalar-vector kernels under Prover::prove, ref: tests/edwards_point.rs:47):
+ * with BPG_TIME_KERNELS=1 in the environment at bpg_init, a single bpg_prover_prove times six of its kernels with HIP
+ * events on their dispatches -- k_zpow, k_flatten, k_poly, k_eval, and k_ipp_rows / k_ipp_fold of the first inner-product
+ * round -- and keeps, per kernel, the microseconds, the bytes it has to move (every input read once, every output written
+ * once) and its multiplications mod l (one Montgomery pass = 104 multiply-adds).  BPG_EINVAL if the last prove was not timed. */
+int bpg_prover_kernel_timing(const bpg_prover *p, double out_us[6], double out_bytes[6], double out_montmuls[6]);
+
 /* Transcript::new(label) + Verifier::new(&mut transcript)   ref: tests/edwards_point.rs:59-61 */
 int bpg_verifier_new(const uint8_t *label, size_t label_len, bpg_verifier **out);
 void bpg_verifier_free(bpg_verifier *v);

@@ -79,6 +79,7 @@ extern "C" {
                                  proofs_out: *mut u8, cap_each: usize, proof_lens: *mut usize) -> c_int;
     pub fn bpg_prover_stats(p: *const bpg_prover, multipliers: *mut usize, constraints: *mut usize) -> c_int;
     pub fn bpg_prover_timing(p: *const bpg_prover, out_ms: *mut c_double) -> c_int;
+    pub fn bpg_prover_kernel_timing(p: *const bpg_prover, out_us: *mut c_double, out_bytes: *mut c_double, out_montmuls: *mut c_double) -> c_int;
     // ---- verifier
     pub fn bpg_verifier_new(label: *const u8, label_len: usize, out: *mut *mut bpg_verifier) -> c_int;
     pub fn bpg_verifier_free(v: *mut bpg_verifier);

@@ -1,6 +1,10 @@
-//! The reference's gadget library (`bulletproofs_gadgets::gadgets`), same names and call order; the circuits are
-//! built inside `libbpg.so` call for call as the reference builds them (ref: src/gadgets/**), so multiplier and
-//! constraint numbering -- and with it the proof bytes -- are the reference's.
+//! OPTIONAL fast path, not part of the `bulletproofs` API: the reference's gadgets (`bulletproofs_gadgets::gadgets`) as
+//! single library calls.  The circuits are built inside `libbpg.so` call for call as the reference builds them
+//! (ref: src/gadgets/**), so multiplier and constraint numbering -- and with it the proof bytes -- are the
+//! reference's; what a caller saves is one FFI crossing per `multiply` / `constrain` (27 multipliers per bit of a
+//! scalar multiplication).  A gadget here is an opaque handle to four linear combinations held by the library: code
+//! that builds `SonnyEdwardsPointGadget { X, Y, Z, T }` literals (ref: tests/edwards_point.rs:36-41) stays on the
+//! reference's own gadget source over `crate::r1cs`.
 use std::ptr;
 
 use bpg_sys as sys;

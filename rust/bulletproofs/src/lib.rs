@@ -1,12 +1,15 @@
-//! `bulletproofs`-shaped API over `libbpg.so`: the R1CS prover and verifier of
-//! dusk-network/bulletproofs_gadgets' hot path on an AMD MI355X.
+//! The `bulletproofs` crate as dusk-network/bulletproofs_gadgets sees it, over `libbpg.so`: the R1CS prover and
+//! verifier of the reference's hot path on an AMD MI355X.
 //!
-//! The names and call shapes are those the reference's gadgets and tests use
-//! (ref: tests/edwards_point.rs:8-15, src/gadgets/sk_knowledge/sk_know_gadget.rs:5-8), so switching is a matter of
-//! `use` lines; see `rust/README.md`.  Not compiled in this repository's image (no Rust toolchain there).
+//! Crate name, module paths, type names and call shapes are those the reference imports
+//! (ref: src/gadgets/boolean.rs:1-5, scalar.rs:1-4, point/edwards_point.rs:2-4, point/ristretto_point.rs:2-4,
+//! sk_knowledge/sk_know_gadget.rs:5-8, tests/edwards_point.rs:8-9): with the `[patch]` lines of `rust/README.md` the
+//! reference's own `src/gadgets/**` and `tests/**` build unmodified and ARE the gadget layer; every
+//! `cs.multiply` / `cs.constrain` / `cs.allocate_multiplier` they make crosses the C ABI.  `fast` holds the same
+//! gadgets as single library calls (optional).  Not compiled in this repository's image (no Rust toolchain there).
 #![allow(non_snake_case)]
 
-pub mod gadgets;
+pub mod fast;
 pub mod r1cs;
 
 use std::ffi::CStr;
@@ -85,16 +88,5 @@ impl BulletproofGens {
     pub fn new(gens_capacity: usize, party_capacity: usize) -> Self {
         assert_eq!(party_capacity, 1, "R1CS proofs use a single party's generators");
         BulletproofGens { gens_capacity, party_capacity, gens: make_gens(gens_capacity) }
-    }
-}
-
-/// Stands where `merlin::Transcript` stands in the reference's code: `Transcript::new(b"label")` handed to
-/// `Prover::new` / `Verifier::new`.  The Merlin state itself lives inside the library's prover / verifier.
-pub struct Transcript {
-    pub(crate) label: &'static [u8],
-}
-impl Transcript {
-    pub fn new(label: &'static [u8]) -> Self {
-        Transcript { label }
     }
 }

@@ -9,7 +9,9 @@ use curve25519_dalek::ristretto::CompressedRistretto;
 use curve25519_dalek::scalar::Scalar;
 use rand::{CryptoRng, RngCore};
 
-use crate::{BulletproofGens, PedersenGens, Transcript};
+use merlin::Transcript;
+
+use crate::{BulletproofGens, PedersenGens};
 
 /// `bulletproofs::r1cs::R1CSError` (the reference matches on `VerificationError`, tests/edwards_point.rs:346).
 #[derive(Clone, Debug, Eq, PartialEq)]
@@ -259,7 +261,7 @@ pub struct Prover<'a, 'b> {
 impl<'a, 'b> Prover<'a, 'b> {
     pub fn new(pc_gens: &'b PedersenGens, transcript: &'a mut Transcript) -> Self {
         let mut raw = ptr::null_mut();
-        let rc = unsafe { sys::bpg_prover_new(pc_gens.gens.0, transcript.label.as_ptr(), transcript.label.len(), &mut raw) };
+        let rc = unsafe { sys::bpg_prover_new(pc_gens.gens.0, transcript.bpg_label().as_ptr(), transcript.bpg_label().len(), &mut raw) };
         check(rc).expect("Prover::new");
         Prover { raw, callbacks: Vec::new(), _life: PhantomData }
     }
@@ -318,7 +320,7 @@ pub struct Verifier<'a> {
 impl<'a> Verifier<'a> {
     pub fn new(transcript: &'a mut Transcript) -> Self {
         let mut raw = ptr::null_mut();
-        check(unsafe { sys::bpg_verifier_new(transcript.label.as_ptr(), transcript.label.len(), &mut raw) }).expect("Verifier::new");
+        check(unsafe { sys::bpg_verifier_new(transcript.bpg_label().as_ptr(), transcript.bpg_label().len(), &mut raw) }).expect("Verifier::new");
         Verifier { raw, callbacks: Vec::new(), _life: PhantomData }
     }
 
