@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <sys/prctl.h>
 
 #include "bpg_internal.h"
 
@@ -218,11 +219,18 @@ hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev) {
     hipError_t e;
     for (int spin = 0; spin < 20; spin++)
         if ((e = hipEventQuery(ev)) != hipErrorNotReady) return e;
-    long ns = 20000;
+    static const long nap0 = getenv("BPG_NAP0") ? atol(getenv("BPG_NAP0")) : 20000, nap1 = getenv("BPG_NAP1") ? atol(getenv("BPG_NAP1")) : 100000;
+    static const long slack = getenv("BPG_SLACK") ? atol(getenv("BPG_SLACK")) : 0;
+    static thread_local bool slack_set = false;
+    if (slack && !slack_set) {
+        slack_set = true;
+        prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+    }
+    long ns = nap0;
     while ((e = hipEventQuery(ev)) == hipErrorNotReady) {
         struct timespec ts = {0, ns};
         nanosleep(&ts, nullptr);
-        if (ns < 100000) ns += 10000;
+        if (ns < nap1) ns += 10000;
     }
     return e;
 }

@@ -1127,6 +1127,8 @@ static int auto_window(size_t n) {
 // bucket overhead is paid once, not per window)
 // (at most 32 windows: the entry word keeps the window in 5 bits)
 int fixed_base_window(size_t points) {
+    if (points > ((size_t)1 << 12))
+        if (const char *e = getenv("BPG_FB_C")) return atoi(e);
     if (points <= ((size_t)1 << 12)) return 9;
     if (points <= ((size_t)1 << 15)) return 12;
     return 14;
