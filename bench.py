@@ -480,10 +480,10 @@ def main():
             gens_s = time.perf_counter() - t0
             stmt = sp.statement(nbits)
             best = None
-            for _ in range(2):
+            for _ in range(3):
                 barrier()
                 proof, cap_s, prove_s, verify_s, tm = sp.prove_and_verify(g, gens, nbits, stmt)
-                if best is None or prove_s < best[1]:
+                if best is None or cap_s + prove_s < best[0] + best[1]:
                     best = (cap_s, prove_s, verify_s, tm)
             gens.free()
             import hashlib
@@ -494,13 +494,19 @@ def main():
                    "proof_sha256": hashlib.sha256(proof.to_bytes()).hexdigest()}
             # what every rank repeats whatever N is: circuit capture + commitments, and the blinding draw (one
             # sequential Keccak chain; bit-exactness fixes its order).  The MSMs are what the ranks split.
-            serial = best[0] + best[3].get("rng_ms", 0.0) / 1e3
+            # The draws start right after the commitments, on a helper thread beside the capture
+            # (bpg_prover_begin_blindings), so the floor is the longer of the two, not their sum.
+            early = os.environ.get("BPG_EARLY_BLINDINGS", "1") != "0"
+            chain = best[3].get("rng_ms", 0.0) / 1e3
+            serial = max(best[0], chain) if early else best[0] + chain
             total = best[0] + best[1]
+            big["early_blindings"] = early
+            big["blinding_chain_s"] = round(chain, 4)
             big["host_serial_s"] = round(serial, 4)
             big["amdahl_bound"] = {"total_s_at_this_n": round(total, 4),
                                    "speedup_limit_8_ranks": round(total / (serial + (total - serial) / 8), 2),
-                                   "note": "capture + commit and the blinding RNG run on every rank; only the remainder (MSMs, "
-                                           "scalar-vector kernels) can shrink with N"}
+                                   "note": "capture + commit and the blinding RNG (one sequential Keccak chain, beside the capture on a helper "
+                                           "thread) run on every rank; only the remainder (MSMs, scalar-vector kernels) can shrink with N"}
         except Exception as e:  # noqa: BLE001  (the headline line must survive a failure here)
             big = {"error": repr(e)}
     # ---- BASELINE configs[4]: 4096 Ristretto-gadget proofs per GPU, verified by one combined MSM (no collective)

@@ -86,6 +86,7 @@ def lib():
         "bpg_prover_commit_batch": (ci, [vp, cp, cp, sz, vp, u64p]),
         "bpg_prover_prove": (ci, [vp, RNG_FN, vp, vp, sz, psz]),
         "bpg_prover_prove_many": (ci, [vp, sz, RNG_FN, vp, vp, sz, psz]),
+        "bpg_prover_begin_blindings": (ci, [vp, cp]),
         "bpg_prover_stats": (ci, [vp, psz, psz]),
         "bpg_prover_timing": (ci, [vp, dp]),
         "bpg_prover_kernel_timing": (ci, [vp, dp, dp, dp]),

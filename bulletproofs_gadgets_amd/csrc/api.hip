@@ -430,6 +430,9 @@ void bpg_shutdown(bpg_ctx *ctx) {
         g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
     }
     forget_shapes_of(ctx->id);
+    for (auto &b : ctx->spec_pool)
+        if (b.first) (void)hipHostFree(b.first);
+    ctx->spec_pool.clear();
     for (auto *lane : ctx->lanes) {
         for (auto *j : lane->jobs) msm_job_destroy(j);
         (void)hipStreamSynchronize(lane->stream);

@@ -178,6 +178,9 @@ struct bpg_ctx {
     std::vector<std::shared_ptr<void>> flat_cache;
     std::atomic<uint64_t> flat_hits{0}, flat_misses{0};
     std::atomic<uint64_t> flat_followed{0};          // hits found by following the cached circuit during capture (no hash, no compare)
+    // pinned buffers of early blinding draws (r1cs.hip: Prover::begin_blindings), kept for the next large proof
+    std::mutex spec_mu;
+    std::vector<std::pair<void *, size_t>> spec_pool;
 };
 
 namespace bpg {

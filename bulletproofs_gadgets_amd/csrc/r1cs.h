@@ -18,6 +18,8 @@
 #include <string>
 #include <stdexcept>
 #include <unordered_map>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "bpg_internal.h"
@@ -378,9 +380,35 @@ struct R1CSProof {
 // external randomness (the reference passes &mut thread_rng(), ref: tests/edwards_point.rs:79)
 typedef void (*rng_fill_fn)(void *user, uint8_t *out, size_t n);
 
+// The blinding draws of ONE large proof, started early (Prover::begin_blindings): a helper thread runs the prover's
+// transcript RNG -- one Keccak permutation per 64-byte draw, strictly sequential: 0.42 s of a 0.67 s proof at 2^20
+// multipliers -- while the caller's thread is still capturing the circuit, and prove() then uploads the draws in chunks as
+// they appear.  The stream does not depend on the circuit, only its length does (3 + 2 n draws), so the helper may
+// always run up to twice the multipliers captured so far.
+struct BlindingSpec {
+    std::thread th;
+    std::atomic<size_t> limit{0};         // raw draws the helper may produce: 2 x the multipliers captured so far; 2 n once final
+    std::atomic<size_t> done{0};          // raw draws delivered (64-byte slots of `raw`, s_L then s_R)
+    std::atomic<bool> heads{false};       // i_bl, o_bl, s_bl drawn
+    std::atomic<bool> final_{false}, cancel{false};
+    bool failed = false;                  // the helper could not get its pinned buffer (read after join)
+    uint8_t *raw = nullptr;               // pinned, `slots` x 64 bytes, from the context's pool
+    size_t slots = 0;
+    sc i_bl, o_bl, s_bl;
+    std::unique_ptr<TranscriptRng> rng;   // the prover's RNG while the helper runs; handed back at exactly 3 + 2 n draws
+    bpg_ctx *ctx = nullptr;
+    double busy_ms = 0;                   // the helper's drawing time
+};
+
 class Prover : public ConstraintSystem {
   public:
     Prover(Gens *gens, const void *label, size_t label_len);
+    ~Prover() { cancel_blindings(); }
+    // Hand over the 32 bytes of external randomness NOW instead of at prove() (which then does not call its rng), and
+    // start drawing blinding factors on a helper thread.  For one large proof proved by prove(): call it after the
+    // last commit and before the gadget calls.  A later commit, or a registration of randomized constraints, stops
+    // the helper and prove() draws as usual, from the same 32 bytes: the proof's bytes are the same either way.
+    int begin_blindings(const uint8_t ext32[32]);
     // Prover::commit; V32 receives the compressed commitment
     Variable commit(const Scalar &v, const Scalar &v_blinding, uint8_t V32[32]);
     // batch form: one GPU launch for m commitments, transcript order preserved
@@ -403,6 +431,7 @@ class Prover : public ConstraintSystem {
     // randomizable.  Here the handle is the same object, so the second phase refuses it instead of dropping it.)
     void specify_randomized_constraints(RandomizedFn cb) override {
         if (phase2_) throw R1CSError(BPG_EINVAL, "specify_randomized_constraints inside a randomized-constraints callback");
+        cancel_blindings();
         deferred_.push_back(std::move(cb));
     }
     Scalar challenge_scalar(const std::string &label) override;
@@ -455,6 +484,13 @@ class Prover : public ConstraintSystem {
     // one-phase proofs of RAW_DRAW_MIN multipliers or more keep the blinding draws as the RNG delivers them -- 64
     // bytes each, s_L then s_R -- and a kernel reduces them mod l (k_reduce512): on the host that reduction is about
     // half of the drawing time once eight Keccak states advance per permutation
+    std::unique_ptr<BlindingSpec> spec_;  // begin_blindings: the helper and its draws
+    bool ext_seeded_ = false;             // begin_blindings has taken the external randomness: prove() does not ask its rng
+    uint8_t ext_[32];
+    void cancel_blindings();
+    void publish_multipliers() {
+        if (spec_) spec_->limit.store(2 * a_L_.size(), std::memory_order_release);
+    }
     std::vector<uint8_t> s_raw_;
     uint8_t *s_raw_pin_ = nullptr;        // the same 128 n bytes in the lane's pinned staging instead (not owned; valid from the draw to the upload)
     static constexpr size_t RAW_DRAW_MIN = 256;

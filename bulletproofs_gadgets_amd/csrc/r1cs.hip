@@ -1221,6 +1221,7 @@ void Prover::commit_batch(const Scalar *v, const Scalar *v_blinding, size_t m, u
         vr[2 * i] = v[i].v;
         vr[2 * i + 1] = v_blinding[i].v;
     }
+    cancel_blindings();                  // a commitment changes the transcript the early draws started from
     HostPhase hp(HostPhase::CAPTURE_COMMIT);
     int rc = pedersen_batch(gens_, vr.data(), m, V32);
     if (rc) throw R1CSError(rc, "pedersen commitment kernel failed");
@@ -1278,6 +1279,7 @@ ConstraintSystem::Triple Prover::multiply(const LinearCombination &left, const L
     a_O_.push_back(o.v);
     cs_.push(left, a_L_.size(), v_.size(), &t.l);          // left - a_L[i] = 0
     cs_.push(right, a_L_.size(), v_.size(), &t.r);         // right - a_R[i] = 0
+    publish_multipliers();
     return t;
 }
 
@@ -1287,6 +1289,7 @@ ConstraintSystem::Triple Prover::allocate_multiplier(const Scalar *left, const S
     a_L_.push_back(left->v);
     a_R_.push_back(right->v);
     a_O_.push_back(((*left) * (*right)).v);
+    publish_multipliers();
     return Triple{{VAR_LEFT, i}, {VAR_RIGHT, i}, {VAR_OUTPUT, i}};
 }
 
@@ -1401,6 +1404,101 @@ int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     return prove_finish(P);
 }
 
+// ---- early blinding draws (one large proof; see BlindingSpec)
+static void spec_release(BlindingSpec &sp) {
+    if (!sp.raw) return;
+    std::lock_guard<std::mutex> lk(sp.ctx->spec_mu);
+    sp.ctx->spec_pool.emplace_back(sp.raw, sp.slots);
+    sp.raw = nullptr;
+}
+
+static void spec_run(BlindingSpec *sp, int device, std::vector<sc> v_blinding, const uint8_t *ext32) {
+    const double t0 = now_ms();
+    for (const sc &vb : v_blinding) {             // (one permutation each: 8 ms for the 38 836 commitments of a 2^20-multiplier proof)
+        uint8_t b[32];
+        sc_tobytes(b, vb);
+        sp->rng->rekey_with_witness_bytes("v_blinding", b, 32);
+    }
+    sp->rng->finalize(ext32);
+    {   // a pinned buffer of the context's pool that is large enough, else a new one (this thread pays for the pinning)
+        std::lock_guard<std::mutex> lk(sp->ctx->spec_mu);
+        auto &pool = sp->ctx->spec_pool;
+        for (size_t i = 0; i < pool.size(); i++)
+            if (pool[i].second >= sp->slots) {
+                sp->raw = (uint8_t *)pool[i].first;
+                sp->slots = pool[i].second;
+                pool.erase(pool.begin() + i);
+                break;
+            }
+    }
+    if (!sp->raw) {
+        void *p = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&p, sp->slots * 64, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            sp->failed = true;
+            sp->heads.store(true, std::memory_order_release);
+            return;
+        }
+        sp->raw = (uint8_t *)p;
+    }
+    sp->i_bl = sp->rng->scalar();
+    sp->o_bl = sp->rng->scalar();
+    sp->s_bl = sp->rng->scalar();
+    sp->heads.store(true, std::memory_order_release);
+    size_t k = 0;
+    while (!sp->cancel.load(std::memory_order_acquire)) {
+        const bool fin = sp->final_.load(std::memory_order_acquire);       // read before the limit: final => the limit is 2 n
+        size_t lim = sp->limit.load(std::memory_order_acquire);
+        if (lim > sp->slots) lim = sp->slots;
+        if (k < lim) {
+            const size_t stop = lim - k > 512 ? k + 512 : lim;
+            for (; k < stop; k++) sp->rng->fill_bytes(sp->raw + 64 * k, 64);
+            sp->done.store(k, std::memory_order_release);
+        } else if (fin) {
+            break;
+        } else {                                   // ahead of the capture (it allows ~12 M draws/s, the chain makes 5 M/s): rare
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    sp->busy_ms = now_ms() - t0;
+}
+
+int Prover::begin_blindings(const uint8_t ext32[32]) {
+    if (!ext32) return BPG_EINVAL;
+    if (ext_seeded_ || consumed_ || rng_) {
+        set_last_error_msg("begin_blindings: called twice, or after prove()");
+        return BPG_EINVAL;
+    }
+    memcpy(ext_, ext32, 32);
+    ext_seeded_ = true;
+    if (!deferred_.empty() || !gens_) return BPG_OK;          // two-phase proofs draw in two rounds: no early start
+    std::unique_ptr<BlindingSpec> sp(new BlindingSpec());
+    sp->ctx = gens_->ctx;
+    sp->slots = 2 * gens_->capacity;
+    Transcript t = tr_;                                        // what prove_begin does, on a copy
+    t.append_u64("m", v_.size());
+    sp->rng.reset(new TranscriptRng(t.build_rng()));
+    sp->limit.store(2 * a_L_.size(), std::memory_order_release);
+    BlindingSpec *raw = sp.get();
+    const int device = gens_->ctx->device;
+    try {
+        sp->th = std::thread(spec_run, raw, device, v_blinding_, (const uint8_t *)ext_);     // ext_ outlives the helper (joined by ~Prover)
+    } catch (...) {
+        return BPG_OK;                                         // no helper: prove() draws as usual
+    }
+    spec_ = std::move(sp);
+    return BPG_OK;
+}
+
+void Prover::cancel_blindings() {
+    if (!spec_) return;
+    spec_->cancel.store(true, std::memory_order_release);
+    if (spec_->th.joinable()) spec_->th.join();
+    spec_release(*spec_);
+    spec_.reset();
+}
+
 // ---- transcript RNG (host, sequential Keccak)
 int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
     HostPhase hp(HostPhase::RNG_BEGIN);
@@ -1413,6 +1511,16 @@ int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
     }
     if (gens_->capacity < next_pow2(n ? n : 1)) return BPG_EGENS;
     tr_.append_u64("m", m);
+    if (spec_) {
+        // the helper started from this transcript (a later commit would have stopped it): tell it where the draws end
+        if (!deferred_.empty() || 2 * n > spec_->slots || !raw_draws()) {
+            cancel_blindings();
+        } else {
+            spec_->limit.store(2 * n, std::memory_order_release);
+            spec_->final_.store(true, std::memory_order_release);
+            return BPG_OK;
+        }
+    }
     rng_.reset(new TranscriptRng(tr_.build_rng()));
     for (size_t i = 0; i < m; i++) {
         uint8_t b[32];
@@ -1420,13 +1528,37 @@ int Prover::prove_begin(rng_fill_fn rng_fn, void *rng_user) {
         rng_->rekey_with_witness_bytes("v_blinding", b, 32);
     }
     uint8_t ext[32];
-    rng_fn(rng_user, ext, 32);
+    if (ext_seeded_) memcpy(ext, ext_, 32);
+    else rng_fn(rng_user, ext, 32);
     rng_->finalize(ext);
     return BPG_OK;
 }
 
 // a prover alone: its raw draws take the whole of the lane's pinned staging
 void Prover::draw_blindings() {
+    if (spec_) {                          // the helper has them (or will): finish_group streams its draws to the device
+        while (!spec_->heads.load(std::memory_order_acquire)) {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+        if (!spec_->failed) {
+            i_bl_ = spec_->i_bl;
+            o_bl_ = spec_->o_bl;
+            s_bl_ = spec_->s_bl;
+            return;
+        }
+        // no pinned buffer: the helper has drawn nothing; start over on this thread
+        spec_->th.join();
+        spec_.reset();
+        Transcript t = tr_;               // tr_ holds "m" already
+        rng_.reset(new TranscriptRng(t.build_rng()));
+        for (size_t i = 0; i < v_.size(); i++) {
+            uint8_t b[32];
+            sc_tobytes(b, v_blinding_[i]);
+            rng_->rekey_with_witness_bytes("v_blinding", b, 32);
+        }
+        rng_->finalize(ext_);
+    }
     uint8_t *slot = nullptr;
     if (raw_draws() && gens_)
         if (bpg_lane *lane = lane_of(gens_->ctx))
@@ -1458,6 +1590,8 @@ void Prover::draw_blindings_into(uint8_t *pinned_slot) {
 }
 
 int Prover::prove_many(Prover *const *ps, size_t k, rng_fill_fn rng_fn, void *rng_user, R1CSProof *out) {
+    if (k == 1) return ps[0]->prove(rng_fn, rng_user, out[0]);
+    for (size_t j = 0; j < k; j++) ps[j]->cancel_blindings();       // early draws are for a prover proved alone
     for (size_t j = 0; j < k; j++) {
         int rc = ps[j]->prove_begin(rng_fn, rng_user);
         if (rc) return rc;
@@ -1677,6 +1811,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     BPG_CHECK_HIP(hipMemsetAsync(d_rows_all, 0, g * 3 * N1 * 32, s));
     std::vector<std::vector<sc>> keep_sL(g), keep_sR(g);  // pageable sources of async copies: alive until the sync
     std::vector<std::vector<uint8_t>> keep_raw(g);
+    uint4 *spec_d_raw = nullptr;
+    double spec_wait_ms = 0;                               // of the commit phase: waiting for the helper's draws
     // the witness vectors go through the lane's pinned staging too (one host copy, then DMA)
     uint8_t *h_wit = n && grow_pinned(&lane->h_wit, &lane->h_wit_cap, g * 3 * n * 32) == BPG_OK ? (uint8_t *)lane->h_wit : nullptr;
     for (size_t j = 0; j < g; j++) {
@@ -1713,7 +1849,10 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             if (!h_wit) BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
             BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, hO, n * 32, hipMemcpyHostToDevice, s));
             const uint8_t *raw = p.s_raw_pin_ ? p.s_raw_pin_ : keep_raw[j].empty() ? nullptr : keep_raw[j].data();
-            if (raw) {                               // raw draws: reduced mod l on the device, straight into row 2
+            if (p.spec_) {                           // early draws: streamed below, once A_I and A_O are under way
+                if (g != 1) return BPG_EINVAL;
+                spec_d_raw = (uint4 *)ar.take<uint8_t>(128 * n);
+            } else if (raw) {                        // raw draws: reduced mod l on the device, straight into row 2
                 if (!p.s_raw_pin_ && keep_raw[j].size() != 128 * n) return BPG_EINVAL;
                 p.s_raw_pin_ = nullptr;
                 uint4 *d_raw = (uint4 *)ar.take<uint8_t>(128 * n);
@@ -1734,7 +1873,39 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
 
     // ---- A_I1, A_O1, S1 of every proof: one 3g-target MSM over [B~ | G[0..n) | H[0..n)]
     const double t1 = now_ms();
-    if (!two_phase) {
+    if (spec_d_raw) {
+        // A_I and A_O need none of the s_L / s_R draws: commit them while the helper is still drawing, then stream the
+        // draws to the device in chunks as they appear (reduced mod l there), and commit S when the last one is in
+        Prover &p = *ps[0];
+        BlindingSpec &sp = *p.spec_;
+        msm_seg segs[3] = {pedersen_seg(gens, 1, 1, 0), gen_seg(gens, 0, 0, n, 1), gen_seg(gens, 1, 0, n, 1 + n)};
+        uint8_t o[96];
+        if ((rc = gens_msm(gens, segs, 3, d_rows_all, N1, 2, o))) return rc;
+        const double t_wait0 = now_ms();
+        const size_t total = 2 * n, CH = (size_t)1 << 16;
+        for (size_t up = 0; up < total;) {
+            const size_t want = total - up < CH ? total : up + CH;
+            while (sp.done.load(std::memory_order_acquire) < want) {
+                struct timespec ts = {0, 50000};
+                nanosleep(&ts, nullptr);
+            }
+            BPG_CHECK_HIP(hipMemcpyAsync((uint8_t *)spec_d_raw + 64 * up, sp.raw + 64 * up, 64 * (want - up), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_reduce512, dim3(grid256(want - up)), dim3(256), 0, s, spec_d_raw + 4 * up, pf[0].d_sL + up, (uint32_t)(want - up));
+            BPG_CHECK_HIP(hipGetLastError());
+            up = want;
+        }
+        BPG_CHECK_HIP(lane_sync(lane));
+        sp.th.join();                                  // done == 2 n: the helper has left its loop
+        p.rng_ = std::move(sp.rng);                    // the t blindings come next from the same RNG
+        p.timing.rng_ms = sp.busy_ms;
+        spec_wait_ms = now_ms() - t_wait0;
+        spec_release(sp);
+        p.spec_.reset();
+        if ((rc = gens_msm(gens, segs, 3, d_rows_all + 2 * N1, N1, 1, o + 64))) return rc;
+        memcpy(out[0].A_I1, o, 32);
+        memcpy(out[0].A_O1, o + 32, 32);
+        memcpy(out[0].S1, o + 64, 32);
+    } else if (!two_phase) {
         msm_seg segs[3] = {pedersen_seg(gens, 1, 1, 0), gen_seg(gens, 0, 0, n, 1), gen_seg(gens, 1, 0, n, 1 + n)};
         std::vector<uint8_t> o(96 * g);
         if ((rc = gens_msm(gens, segs, 3, d_rows_all, N1, (int)(3 * g), o.data()))) return rc;

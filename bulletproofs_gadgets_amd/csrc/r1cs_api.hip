@@ -214,6 +214,11 @@ int bpg_prover_timing(const bpg_prover *p, double out_ms[5]) {
     return BPG_OK;
 }
 
+int bpg_prover_begin_blindings(bpg_prover *p, const uint8_t ext32[32]) {
+    if (!p || !ext32) return BPG_EINVAL;
+    return guarded([&] { return p->p->begin_blindings(ext32); });
+}
+
 int bpg_prover_kernel_timing(const bpg_prover *p, double out_us[6], double out_bytes[6], double out_montmuls[6]) {
     if (!p || !out_us || !out_bytes || !out_montmuls) return BPG_EINVAL;
     const auto &k = p->p->ktiming;

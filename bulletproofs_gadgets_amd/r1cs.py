@@ -283,6 +283,15 @@ class Prover(_CS):
         rng.check()
         return Proof(ctypes.string_at(out, n.value))
 
+    def begin_blindings(self, external_rng32):
+        """One large proof: hand the 32 bytes of external randomness over now -- after the last commit, before the
+        gadget calls -- and a helper thread draws the blinding vectors while this thread captures the circuit
+        (bpg_prover_begin_blindings).  prove() then ignores its own external_rng32; the proof's bytes are those of
+        prove(external_rng32=these bytes) without this call."""
+        if len(external_rng32) != 32:
+            raise ValueError("32 bytes of external randomness")
+        check(lib().bpg_prover_begin_blindings(self._h, bytes(external_rng32)))
+
     @staticmethod
     def prove_many(provers, external_rng=None):
         """k proofs by this thread (bpg_prover_prove_many): the bytes of [p.prove() for p in provers] when the

@@ -199,6 +199,16 @@ int bpg_prover_prove(bpg_prover *p, bpg_rng_fn rng, void *rng_user, uint8_t *pro
  * proof_lens[j].  BPG_EINVAL if a proof does not fit cap_each (proof_lens is still set). */
 int bpg_prover_prove_many(bpg_prover *const *provers, size_t k, bpg_rng_fn rng, void *rng_user, uint8_t *proofs_out, size_t cap_each,
                           size_t *proof_lens);
+/* One LARGE proof (ref call site: sk_know_gadget.rs:63, Prover::prove after 256 commits and the scalar_mul gadget; BASELINE
+ * config 4 = 2^20 multipliers): the prover's blinding vectors s_L, s_R come from one transcript RNG, one Keccak
+ * permutation per 64-byte draw, strictly sequential -- 0.42 s on one host core at 2^20, more than capture and GPU work
+ * together.  Upstream's prove() asks thread_rng() for 32 bytes and starts that chain at the top of prove(); this call
+ * hands the same 32 bytes over EARLIER -- after the last commit, before the gadget calls -- so that a helper thread draws
+ * while the caller captures the circuit; bpg_prover_prove then does not call its rng and uploads the draws as they appear.
+ * The proof is byte for byte the one bpg_prover_prove gives with an rng that returns ext32.  A commit or a
+ * specify_randomized_constraints after this call stops the helper (prove draws as usual, still from ext32).
+ * No counterpart call in the reference (its RNG is internal); optional. */
+int bpg_prover_begin_blindings(bpg_prover *p, const uint8_t ext32[32]);
 int bpg_prover_stats(const bpg_prover *p, size_t *multipliers, size_t *constraints);
 /* milliseconds of the last prove(): blinding RNG, A/S commitments, polynomial phase, inner-product argument, total */
 int bpg_prover_timing(const bpg_prover *p, double out_ms[5]);

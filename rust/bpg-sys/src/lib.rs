@@ -77,6 +77,7 @@ extern "C" {
                             proof_len: *mut usize) -> c_int;
     pub fn bpg_prover_prove_many(provers: *const *mut bpg_prover, k: usize, rng: bpg_rng_fn, rng_user: *mut c_void,
                                  proofs_out: *mut u8, cap_each: usize, proof_lens: *mut usize) -> c_int;
+    pub fn bpg_prover_begin_blindings(p: *mut bpg_prover, ext32: *const u8) -> c_int;
     pub fn bpg_prover_stats(p: *const bpg_prover, multipliers: *mut usize, constraints: *mut usize) -> c_int;
     pub fn bpg_prover_timing(p: *const bpg_prover, out_ms: *mut c_double) -> c_int;
     pub fn bpg_prover_kernel_timing(p: *const bpg_prover, out_us: *mut c_double, out_bytes: *mut c_double, out_montmuls: *mut c_double) -> c_int;

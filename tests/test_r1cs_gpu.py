@@ -8,6 +8,8 @@
 """
 import random
 
+import ctypes
+
 import pytest
 
 from oracle import r1cs as R
@@ -550,3 +552,50 @@ def test_circuits_without_multipliers(gbe, obe):
     for n_mult in (0, 1, 3):
         assert _both(rc.linear_only_roundtrip, gbe, obe, 5, 7, 12, n_mult=n_mult)
         assert not _both(rc.linear_only_roundtrip, gbe, obe, 5, 7, 13, n_mult=n_mult)
+
+
+def test_early_blinding_draws_give_the_same_proof(gpu_ctx):
+    """bpg_prover_begin_blindings: the helper thread's draws, streamed to the device during prove(), give the bytes of a
+    plain prove() with the same external randomness -- also when the helper is stopped by a later commit, when the
+    call comes before any gadget call or after all of them, and when the prover is handed to prove_many."""
+    from bulletproofs_gadgets_amd import r1cs as g
+    from tools import sharded_proof as sp
+    nbits = 40                                     # 1084 multipliers: above the raw-draw threshold
+    stmt = sp.statement(nbits)
+    base, expected, vals, bl, ext_p, ext_v = stmt
+    E = g.SonnyEdwardsPointGadget
+    gens = g.BulletproofGens(gpu_ctx, 2048, 1)
+    try:
+        want, *_ = sp.prove_and_verify(g, gens, nbits, stmt, early=False)
+        got, *_ = sp.prove_and_verify(g, gens, nbits, stmt, early=True)
+        assert got.to_bytes() == want.to_bytes()
+
+        def build(when):
+            p = g.Prover(gens, b"ScalarMul")
+            half = len(vals) // 64 * 32
+            if when == "before_last_commit":       # a commit after the call: the helper is stopped, prove() draws itself
+                _, v1 = p.commit_batch_raw(vals[:half], bl[:half])
+                p.begin_blindings(ext_p)
+                _, v2 = p.commit_batch_raw(vals[half:], bl[half:])
+                both = list(v1)[:half // 32] + list(v2)[:nbits - half // 32]
+                vars_ = (ctypes.c_uint64 * nbits)(*both)
+            else:
+                _, vars_ = p.commit_batch_raw(vals, bl)
+            if when == "before_gadget":
+                p.begin_blindings(ext_p)
+            E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
+            if when == "after_gadget":
+                p.begin_blindings(ext_p)
+            return p
+        for when in ("before_gadget", "after_gadget", "before_last_commit"):
+            assert build(when).prove(gens, b"\x55" * 32).to_bytes() == want.to_bytes(), when       # prove's own rng is not asked
+        # prove_many stops the helpers and draws in lock-step, from the bytes handed over early
+        ps = [build("before_gadget"), build("before_gadget")]
+        proofs = g.Prover.prove_many(ps, b"\x55" * 64)
+        assert [q.to_bytes() for q in proofs] == [want.to_bytes()] * 2
+        with pytest.raises(Exception):
+            p = build("before_gadget")
+            p.begin_blindings(ext_p)               # twice
+        del p                                      # a prover dropped with its helper running
+    finally:
+        gens.free()
