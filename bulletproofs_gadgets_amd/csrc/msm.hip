@@ -342,8 +342,10 @@ __global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t *__restrict__ 
 }
 
 // level 1: entries -> bins.  tmp[pos] = (entry, bucket number within the bin); entry = scalar
-// index | sign << 31 (fixed-base mode: also the window << 26, i.e. which block of the shifted
-// table the point comes from)
+// index | sign << 31 (fixed-base mode: also the window << FB_WSHIFT, i.e. which block of the shifted
+// table the point comes from: 25 index bits, 6 window bits)
+constexpr int FB_WSHIFT = 25;
+constexpr uint32_t FB_IDX_MASK = (1u << FB_WSHIFT) - 1u, FB_WMASK = 63u;
 template <bool PACKED>
 __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ bin_off,
                                                      uint32_t *__restrict__ bin_fill, typename sort_item<PACKED>::T *__restrict__ tmp,
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(512) k_bin_scatter(const int16_t *__restrict__
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, t = blockIdx.z;
     const size_t base = (size_t)t * W + w, bset = shared ? (size_t)t : base;
-    const uint32_t wtag = shared ? (uint32_t)w << 26 : 0u;
+    const uint32_t wtag = shared ? (uint32_t)w << FB_WSHIFT : 0u;
     const uint32_t lowmask = (1u << lowshift) - 1u;
     const int16_t *dg = digits + base * n;
     for (int b = threadIdx.x; b < NBIN; b += blockDim.x) lds[b] = 0;
@@ -793,10 +795,10 @@ k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ 
     const uint32_t lo = rank * base + (rank < rem ? rank : rem);
     const uint32_t hi = lo + base + (rank < rem ? 1u : 0u);
     // variable-base: wstride = 0 and the entry is index | sign; fixed-base: window w's copy of point i
-    // (2^(c w) P_i) lives wstride records further per window (<= 28 windows)
+    // (2^(c w) P_i) lives wstride records further per window (<= 64 windows)
     auto record = [&](uint32_t en) {
-        const uint32_t idx = wstride ? (en & 0x03ffffffu) : (en & 0x7fffffffu);
-        const uint32_t win = wstride ? ((en >> 26) & 31u) : 0u;
+        const uint32_t idx = wstride ? (en & FB_IDX_MASK) : (en & 0x7fffffffu);
+        const uint32_t win = wstride ? ((en >> FB_WSHIFT) & FB_WMASK) : 0u;
         return record_of<MULTI>(map, idx) + (size_t)win * wstride;
     };
     ge acc;
@@ -963,24 +965,36 @@ __global__ void __launch_bounds__(320) k_tail_b(const ge_rec *__restrict__ chunk
 // ------------------------------------------------------------------ folded generators
 // G'_i = sum_{j = i mod m} s_j G_j (and H' likewise): 2m sums per scalar row [s_G (np) | s_H (np)], each over
 // np / m generators with full-size scalars, from the fixed-base table (window w of point j is one record).
-// A signed c-bit digit d is cut into 5-bit pieces |d| = p0 + 32 p1 + 1024 p2 (c <= 15), and the window's point
-// goes, with d's sign, into bucket (target, piece t, p_t): 3 x 32 buckets per target.  The sort, accumulate and
-// merge kernels above then run on those bucket numbers, k_fold_sets turns every 32-bucket set into
-// sum_b (b+1) B_b, and k_fold_finish joins the three sets (x 32, x 1024) into one point
-// and writes it as an affine Niels record, ready to be a point of a variable-base MSM.
+// Two bucket layouts (fold_shape):
+//  * narrow digits (c <= 7, read from a table that holds a block per c bits -- the generator table's half windows): a
+//    signed digit |d| <= 2^(c-1) goes, with its sign, into bucket (target, |d| - 1): ONE addition per digit, 2^(c-1)
+//    buckets per target.  At c = 7 a target's 32 generators x 36 windows cost 1152 additions + 128 for the set.
+//  * wide digits (c <= 14, the table's own windows): |d| = p0 + 32 p1 + 1024 p2 is cut into 5-bit pieces and the window's
+//    point goes into bucket (target, piece t, p_t): 3 x 32 buckets per target and THREE additions per digit
+//    (32 x 18 x 3 = 1728 + 192 at c = 14).
+// The sort, accumulate and merge kernels above then run on those bucket numbers, k_fold_sets turns every bucket set
+// into sum_b (b+1) B_b, and k_fold_finish joins a target's sets (x 32, x 1024) into one point and writes it as an
+// affine Niels record, ready to be a point of a later MSM.
+struct fold_shape {
+    int P, PB;                                             // pieces per digit, bits per piece: 2^PB buckets per set
+};
 __device__ __forceinline__ uint32_t fold_target(uint32_t row, uint32_t i, uint32_t np, uint32_t m) {
     const uint32_t side = i >= np ? 1u : 0u, jj = i - side * np;
     return (row * 2u + side) * m + (jj & (m - 1u));
 }
-// bins of 256 buckets = 8 piece sets; one tile (a run of indices of one row, one side, one window) reaches the
-// m * 96 / 256 bins of its (row, side), which is what the LDS cursors cover
+// bucket of piece t (value pc in [1, 2^PB]; a single piece uses all 2^PB slots, 5-bit pieces never reach slot 31)
+__device__ __forceinline__ uint32_t fold_piece(uint32_t a, int t, fold_shape fs) {
+    return fs.P == 1 ? a : (a >> (fs.PB * t)) & ((1u << fs.PB) - 1u);
+}
+// bins of 256 buckets; one tile (a run of indices of one row, one side, one window) reaches the
+// m * P * 2^PB / 256 bins of its (row, side), which is what the LDS cursors cover
 __global__ void __launch_bounds__(512) k_fold_hist(const int16_t *__restrict__ digits, uint32_t *__restrict__ bin_counts, size_t n,
-                                                   int W, uint32_t np, uint32_t m, int tile) {
+                                                   int W, uint32_t np, uint32_t m, int tile, fold_shape fs) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, row = blockIdx.z;
     const int16_t *dg = digits + ((size_t)row * W + w) * n;
     const uint32_t start = blockIdx.x * (uint32_t)tile, end = start + tile < n ? start + tile : (uint32_t)n;
-    const uint32_t nb = m * 96u / 256u;                      // bins per (row, side)
+    const uint32_t nb = ((m * (uint32_t)fs.P) << fs.PB) >> 8;                      // bins per (row, side)
     const uint32_t binbase = ((uint32_t)row * 2u + (start >= np ? 1u : 0u)) * nb;
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
     __syncthreads();
@@ -989,10 +1003,9 @@ __global__ void __launch_bounds__(512) k_fold_hist(const int16_t *__restrict__ d
         const int d = i < end ? dg[i] : 0;
         const uint32_t a = (uint32_t)(d < 0 ? -d : d);
         const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t pc = (a >> (5 * t)) & 31u;
-            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+        for (int t = 0; t < fs.P; t++) {
+            const uint32_t pc = fold_piece(a, t, fs);
+            const uint32_t g = ((tg * (uint32_t)fs.P + t) << fs.PB) + pc - 1u;
             (void)lds_claim(lds, (g >> 8) - binbase, pc != 0);
         }
     }
@@ -1004,12 +1017,12 @@ __global__ void __launch_bounds__(512) k_fold_hist(const int16_t *__restrict__ d
 }
 __global__ void __launch_bounds__(512) k_fold_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ bin_off,
                                                       uint32_t *__restrict__ bin_fill, uint2 *__restrict__ tmp, size_t n, int W,
-                                                      uint32_t np, uint32_t m, int tile) {
+                                                      uint32_t np, uint32_t m, int tile, fold_shape fs) {
     extern __shared__ uint32_t lds[];
     const int w = blockIdx.y, row = blockIdx.z;
     const int16_t *dg = digits + ((size_t)row * W + w) * n;
     const uint32_t start = blockIdx.x * (uint32_t)tile, end = start + tile < n ? start + tile : (uint32_t)n;
-    const uint32_t nb = m * 96u / 256u;
+    const uint32_t nb = ((m * (uint32_t)fs.P) << fs.PB) >> 8;
     const uint32_t binbase = ((uint32_t)row * 2u + (start >= np ? 1u : 0u)) * nb;
     for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
     __syncthreads();
@@ -1018,10 +1031,9 @@ __global__ void __launch_bounds__(512) k_fold_scatter(const int16_t *__restrict_
         const int d = i < end ? dg[i] : 0;
         const uint32_t a = (uint32_t)(d < 0 ? -d : d);
         const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t pc = (a >> (5 * t)) & 31u;
-            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+        for (int t = 0; t < fs.P; t++) {
+            const uint32_t pc = fold_piece(a, t, fs);
+            const uint32_t g = ((tg * (uint32_t)fs.P + t) << fs.PB) + pc - 1u;
             (void)lds_claim(lds, (g >> 8) - binbase, pc != 0);
         }
     }
@@ -1036,27 +1048,26 @@ __global__ void __launch_bounds__(512) k_fold_scatter(const int16_t *__restrict_
         const int d = i < end ? dg[i] : 0;
         const uint32_t a = (uint32_t)(d < 0 ? -d : d);
         const uint32_t tg = fold_target(row, i < end ? i : start, np, m);
-        const uint32_t entry = i | ((uint32_t)w << 26) | (d < 0 ? 0x80000000u : 0u);
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t pc = (a >> (5 * t)) & 31u;
-            const uint32_t g = ((tg * 3u + t) << 5) + pc - 1u;
+        const uint32_t entry = i | ((uint32_t)w << FB_WSHIFT) | (d < 0 ? 0x80000000u : 0u);
+        for (int t = 0; t < fs.P; t++) {
+            const uint32_t pc = fold_piece(a, t, fs);
+            const uint32_t g = ((tg * (uint32_t)fs.P + t) << fs.PB) + pc - 1u;
             const uint32_t pos = lds_claim(lds, (g >> 8) - binbase, pc != 0);
             if (pc != 0) tmp[pos] = make_uint2(entry, g & 255u);
         }
     }
 }
-// one thread per piece set: sum_b (b + 1) B_b over its 32 buckets by running sums (a 32-thread bit tree per set,
+// one thread per bucket set: sum_b (b + 1) B_b over its 2^PB buckets by running sums (a 32-thread bit tree per set,
 // k_tail_a's way, took 1.9 ms for the 98 k sets of eight 2^16-multiplier proofs; this takes a tenth)
 __global__ void __launch_bounds__(256) k_fold_sets(levels_dev L, const uint32_t *__restrict__ counts, uint32_t nsets,
-                                                  ge_rec *__restrict__ out, int ls0, int ls1) {
+                                                  ge_rec *__restrict__ out, int ls0, int ls1, int PB) {
     const uint32_t st = blockIdx.x * 256u + threadIdx.x;
     if (st >= nsets) return;
     ge run, acc, b;
     ge_identity(run);
     ge_identity(acc);
-    for (int k = 31; k >= 0; k--) {
-        const size_t g = (size_t)st * 32 + k;
+    for (int k = (1 << PB) - 1; k >= 0; k--) {
+        const size_t g = ((size_t)st << PB) + k;
         if (counts[g]) {
             bucket_sum(b, L, counts, g, ls0, ls1);
             ge_add(run, run, b);
@@ -1066,17 +1077,18 @@ __global__ void __launch_bounds__(256) k_fold_sets(levels_dev L, const uint32_t 
     store_ge(out + st, acc);
 }
 // sets: [target][piece] as k_fold_sets leaves them; one thread per target
-__global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ sets, uint32_t ntargets, aniels_rec *__restrict__ tab) {
+__global__ void __launch_bounds__(256) k_fold_finish(const ge_rec *__restrict__ sets, uint32_t ntargets, aniels_rec *__restrict__ tab,
+                                                    fold_shape fs) {
     const uint32_t tg = blockIdx.x * 256u + threadIdx.x;
     if (tg >= ntargets) return;
     ge p;
-    for (int t = 2; t >= 0; t--) {
+    for (int t = fs.P - 1; t >= 0; t--) {
         ge v;
-        load_ge(v, sets + (size_t)tg * 3 + t);
-        if (t == 2) {
+        load_ge(v, sets + (size_t)tg * fs.P + t);
+        if (t == fs.P - 1) {
             p = v;
         } else {
-            for (int k = 0; k < 5; k++) ge_double(p, p);
+            for (int k = 0; k < fs.PB; k++) ge_double(p, p);
             ge_add(p, p, v);
         }
     }
@@ -1127,8 +1139,6 @@ static int auto_window(size_t n) {
 // bucket overhead is paid once, not per window)
 // (at most 32 windows: the entry word keeps the window in 5 bits)
 int fixed_base_window(size_t points) {
-    if (points > ((size_t)1 << 12))
-        if (const char *e = getenv("BPG_FB_C")) return atoi(e);
     if (points <= ((size_t)1 << 12)) return 9;
     if (points <= ((size_t)1 << 15)) return 12;
     return 14;
@@ -1490,7 +1500,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
                bpg_msm_job **out_job, msm_fixed_base fb, size_t sc_stride) {
     if (!ctx || !segs || !out_job || T < 1 || nseg < 1 || nseg > 4) return BPG_EINVAL;
     if (sc_stride && scalars_on_host) return BPG_EINVAL;
-    if (n >= ((size_t)1 << 28) || (fb.c && (n >= ((size_t)1 << 26) || fb.wstride >= ((size_t)1 << 32)))) return BPG_EINVAL;
+    if (n >= ((size_t)1 << 28) || (fb.c && (n >= ((size_t)1 << FB_WSHIFT) || fb.wstride >= ((size_t)1 << 32)))) return BPG_EINVAL;
     msm_maps mm{};
     int rc;
     if ((rc = msm_make_maps(segs, nseg, n, sc_stride, mm))) return rc;
@@ -1680,7 +1690,8 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
                     msm_fixed_base fb, aniels_rec *d_tab, bpg_msm_job **out_job) {
     if (!ctx || !segs || !d_scalars || !d_tab || !out_job || rows < 1) return BPG_EINVAL;
     if (fb.c < 2 || fb.c > 14 || !fb.wstride) return BPG_EINVAL;                      // three 5-bit pieces cover |d| <= 2^13
-    if (np < m || m < 32 || (m & (m - 1)) || (np & (np - 1)) || np > ((size_t)1 << 25)) return BPG_EINVAL;
+    const fold_shape fs = fb.c <= 7 ? fold_shape{1, fb.c - 1} : fold_shape{3, 5};
+    if (np < m || m < 32 || (m & (m - 1)) || (np & (np - 1)) || np > ((size_t)1 << (FB_WSHIFT - 1))) return BPG_EINVAL;
     if (segs[0].len != np || segs[1].len != np || !segs[0].base || !segs[1].base) return BPG_EINVAL;
     const size_t n = 2 * np;
     if (stride < n || stride >= ((size_t)1 << 32)) return BPG_EINVAL;
@@ -1690,9 +1701,10 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     if (!j) return BPG_EDEVICE;
     const int c = fb.c, W = windows_for(c);
     const int S0 = 16, LS1 = 4;
-    const size_t ntargets = (size_t)rows * 2 * m, sets = ntargets * 3;
-    const size_t NE = sets * 32;                           // buckets
-    const size_t M = (size_t)rows * 3 * W * n;             // upper bound on entries
+    const size_t ntargets = (size_t)rows * 2 * m, sets = ntargets * fs.P;
+    const size_t NE = sets << fs.PB;                       // buckets
+    const size_t M = (size_t)rows * fs.P * W * n;          // upper bound on entries
+    if (W > (int)FB_WMASK + 1 || n > ((size_t)1 << FB_WSHIFT) || (((m * fs.P) << fs.PB) & 255)) return BPG_EINVAL;
     if (M >= ((size_t)1 << 32) || NE >= ((size_t)1 << 30)) return BPG_EINVAL;
     // merge passes: a bucket holds at most (np / m) * W entries
     const size_t worst = (np / m) * (size_t)W;
@@ -1764,11 +1776,11 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     uint2 *tmp = (uint2 *)j->d_tmp;
     dispatch_digits(c, s, (const uint32_t *)d_scalars, j->d_digits, n, (size_t)rows * n, smap, bin_counts, (uint32_t)(2 * NBT));
     dim3 tgrid(ntiles, W, rows);
-    const size_t bin_lds = (m * 96 / 256) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_fold_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, W, (uint32_t)np, (uint32_t)m, tile);
+    const size_t bin_lds = (((m * fs.P) << fs.PB) >> 8) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_fold_hist, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_counts, n, W, (uint32_t)np, (uint32_t)m, tile, fs);
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, s, bin_counts, bin_off, chunk_off, (uint32_t)NBT, CH);
     hipLaunchKernelGGL(k_fold_scatter, tgrid, dim3(512), bin_lds, s, j->d_digits, bin_off, bin_fill, tmp, n, W, (uint32_t)np,
-                       (uint32_t)m, tile);
+                       (uint32_t)m, tile, fs);
     hipLaunchKernelGGL(k_chunk_count<false>, dim3((unsigned)NCH), dim3(256), 0, s, bin_off, chunk_off, tmp, chunk_hist, counts, ent_off,
                        j->d_entries, (uint32_t)NBT, CH, LOWN);
     hipLaunchKernelGGL(k_chunk_offsets, dim3((unsigned)(NBT < 512 ? NBT : 512)), dim3(256), 0, s, bin_off, chunk_off, chunk_hist, counts,
@@ -1800,8 +1812,8 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((cap_lv[r] + 255) / 256)), dim3(256), 0, s, counts, L.lv[r - 1], L.lv[r], mp,
                            j->d_partials + part_off[r - 1], j->d_partials + part_off[r], (uint32_t)nblk, (uint32_t)NE, r, S0, LS1);
     }
-    hipLaunchKernelGGL(k_fold_sets, dim3((unsigned)((sets + 255) / 256)), dim3(256), 0, s, L, counts, (uint32_t)sets, j->d_out, S0, LS1);
-    hipLaunchKernelGGL(k_fold_finish, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, j->d_out, (uint32_t)ntargets, d_tab);
+    hipLaunchKernelGGL(k_fold_sets, dim3((unsigned)((sets + 255) / 256)), dim3(256), 0, s, L, counts, (uint32_t)sets, j->d_out, S0, LS1, fs.PB);
+    hipLaunchKernelGGL(k_fold_finish, dim3((unsigned)((ntargets + 255) / 256)), dim3(256), 0, s, j->d_out, (uint32_t)ntargets, d_tab, fs);
     FOLD_CHECK_HIP(hipGetLastError());
     FOLD_CHECK_HIP(hipEventRecord(j->ev[3], s));
     return BPG_OK;

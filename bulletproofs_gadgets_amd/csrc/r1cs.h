@@ -354,8 +354,14 @@ struct Gens {
     int rank = 0, world = 1;
     exchange_fn exchange = nullptr;
     void *exchange_user = nullptr;
-    // fixed-base MSM: the table holds fb_windows blocks of npoints() records, block w = 2^(fb_c w) * block 0
+    // fixed-base MSM: the table holds tab_blocks blocks of npoints() records, block w = 2^(tab_c w) * block 0.  The MSMs
+    // of commitments, inner-product rounds and verification read windows of fb_c bits; where a prover can come to
+    // fold its generators (unsharded, capacity >= 4096) the table also holds the half windows (tab_c = fb_c / 2, twice
+    // the blocks): the fold then spends one addition per 7-bit digit instead of three per 14-bit digit (msm_fold_submit),
+    // and the other MSMs step over every other block (fb_stride).
     int fb_c = 0, fb_windows = 0;
+    int tab_c = 0, tab_blocks = 0;
+    size_t fb_stride() const { return npoints() * (size_t)(fb_c / tab_c); }
     size_t local() const { return hi - lo; }
     size_t npoints() const { return 2 * local() + 2; }
     size_t off_G() const { return 0; }              // record of G_lo

@@ -1061,7 +1061,10 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, 
     g->table = tbl;
     g->fb_c = fixed_base_window(tbl->n);
     g->fb_windows = fixed_base_windows(g->fb_c);
-    hipError_t e = device_malloc((void **)&tbl->d_table, (size_t)g->fb_windows * tbl->n * sizeof(aniels_rec));
+    g->tab_c = g->fb_c;
+    if (world == 1 && capacity >= 4096 && (g->fb_c == 12 || g->fb_c == 14) && !getenv("BPG_NO_HALF_WINDOWS")) g->tab_c = g->fb_c / 2;
+    g->tab_blocks = fixed_base_windows(g->tab_c);
+    hipError_t e = device_malloc((void **)&tbl->d_table, (size_t)g->tab_blocks * tbl->n * sizeof(aniels_rec));
     if (e != hipSuccess) {
         set_last_error("hipMalloc(generator table)", e);
         return BPG_ENOMEM;
@@ -1096,7 +1099,7 @@ int gens_create(bpg_ctx *ctx, size_t capacity, Gens **out, int rank, int world, 
     s3.absorb(Benc, 32);
     s3.squeeze(h, 64);
     if ((rc = table_write_uniform(ctx, tbl->d_table + g->off_Bb(), h, 1))) return rc;
-    if ((rc = table_build_shifted(ctx, tbl->d_table, tbl->n, g->fb_c, g->fb_windows))) return rc;
+    if ((rc = table_build_shifted(ctx, tbl->d_table, tbl->n, g->tab_c, g->tab_blocks))) return rc;
     BPG_CHECK_HIP(device_malloc(&g->d_comb, 2 * 64 * 8 * sizeof(aniels_rec)));
     hipLaunchKernelGGL(k_build_comb, dim3(16), dim3(64), 0, lane->stream, tbl->d_table + g->off_B(), (aniels_rec *)g->d_comb);
     BPG_CHECK_HIP(hipGetLastError());
@@ -1192,7 +1195,7 @@ static int gens_msm(Gens *g, const msm_seg *segs, int nseg, const sc *d_rows, si
     int rc;
     {
         HostPhase hp(ph_submit);
-        rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->npoints(), density}, stride);
+        rc = msm_submit(g->ctx, segs, nseg, d_rows, n, T, false, &job, msm_fixed_base{g->fb_c, g->fb_stride(), density}, stride);
     }
     if (rc) return rc;
     HostPhase hp(ph_wait);
@@ -1392,10 +1395,15 @@ int Prover::two_phase_prologue(R1CSProof &P) {
 }
 
 // Inner-product round after which finish_group materializes the folded generators (0: never; BPG_IPP_FOLD
-// overrides): when 2 x 2048 folded generators are left.  The fold costs about 3.4 rounds' worth of additions
-// whenever it is done; measured at 2^16 multipliers, 16 threads x 8 statements: 204-210 proofs/s without,
-// 211 / 246 / 242 after round 4 / 5 / 6.
-static int ipp_fold_default(size_t lg) { return lg >= 12 ? (int)lg - 11 : 0; }
+// overrides): when 2 x 4096 folded generators are left (2 x 2048 where the table has no half windows, or the group's
+// folded tables would pass 2^17 points).  With half windows the fold costs about 2.2 rounds' worth of additions
+// (3.4 without) whenever it is done; measured at 2^16 multipliers, 64 threads x 8 statements: 421 proofs/s with the
+// three-piece fold after round 5, 452 with the half-window fold after round 5, 462 after round 4.
+static int ipp_fold_default(size_t lg, size_t g, bool half_windows) {
+    if (lg < 12) return 0;
+    const bool wide = half_windows && lg >= 13 && g * 2 * 4096 + 1 <= ((size_t)1 << 17);
+    return (int)lg - (wide ? 12 : 11);
+}
 
 int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     int rc = prove_begin(rng_fn, rng_user);
@@ -1771,15 +1779,18 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
     const size_t nblk_n = grid_strip(n ? n : 1), nblk_np = grid256(np);
     // materialize the folded generators after round k0 (see msm_fold_submit): later rounds run on 2m points per proof
-    int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg) : ctx->tune.ipp_fold;
+    int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg, g, gens->tab_c != gens->fb_c) : ctx->tune.ipp_fold;
     if (gens->world != 1 || k0 < 1 || (size_t)k0 >= lg || (np >> k0) < 32) k0 = 0;
+    // the rounds after the fold need the folded generators' own fixed-base table (below): no fold where that table
+    // would pass 2^17 points or a side keeps more than 4096 generators (sizes this path has not been run at)
+    if (k0 && ((np >> k0) > 4096 || g * 2 * (np >> k0) + 1 > ((size_t)1 << 17))) k0 = 0;
     const size_t fm = k0 ? np >> k0 : 0;                  // folded generators per side
     // The rounds after the fold run FIXED-BASE as well: the folded generators get their own table of 2^(c w) multiples
     // (one doubling chain per point, built once per group).  A variable-base MSM leaves ~250 doublings per target to
     // the host's window combination -- 16 targets x 11 rounds of them were more than half of a group's inner-product
     // latency and 2.8 ms of host CPU per proof; fixed-base leaves c - 1.
     const size_t fpts = g * 2 * fm + 1;                   // [tab_0 | .. | tab_{g-1} | B]
-    const bool fold_fb = k0 && fpts <= ((size_t)1 << 17);
+    const bool fold_fb = k0 != 0;
     const int fold_c = 9, fold_W = fold_fb ? fixed_base_windows(fold_c) : 1;
     // MSM scalar rows: 2g rows of NR before the fold, of g * 2 fm + 1 after it
     const size_t row_words = std::max(g * 2 * NR, 2 * g * (g * 2 * fm + 1));
@@ -2051,7 +2062,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     std::vector<uint8_t> lr(64 * g);
     // until the fold: vectors over the np original generators, rows [G | H | B] of NR scalars.  After it: over
     // the fm folded ones of each proof; the group's tables form one point set [tab_0 | .. | tab_{g-1} | B] and
-    // proof j's two rows are zero outside its own block, so one variable-base MSM still serves the group.
+    // proof j's two rows are zero outside its own block, so one fixed-base MSM over the folded tables still serves the group.
     size_t cnp = np, cstride = NR, cblk = nblk_np;
     ipp_group grp{};
     for (size_t k = 0; k < lg; k++, nk >>= 1) {
@@ -2060,15 +2071,13 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             BPG_CHECK_HIP(lane_sync(lane));         // the folds of round k-1 wrote sG / sH
             msm_seg fs[2] = {gen_seg(gens, 0, 0, np, 0), gen_seg(gens, 1, 0, np, np)};
             bpg_msm_job *job = nullptr;
-            if ((rc = msm_fold_submit(ctx, fs, d_s_all, 2 * np, (int)g, np, fm, msm_fixed_base{gens->fb_c, gens->npoints(), 1.f},
+            if ((rc = msm_fold_submit(ctx, fs, d_s_all, 2 * np, (int)g, np, fm, msm_fixed_base{gens->tab_c, gens->npoints(), 1.f},
                                       d_tab_all, &job)))
                 return rc;
             if ((rc = msm_fold_wait(job))) return rc;
-            if (fold_fb) {
-                BPG_CHECK_HIP(hipMemcpyAsync(d_tab_all + g * 2 * fm, gens->table->d_table + gens->off_B(), sizeof(aniels_rec),
-                                             hipMemcpyDeviceToDevice, s));
-                if ((rc = table_build_shifted(ctx, d_tab_all, fpts, fold_c, fold_W))) return rc;
-            }
+            BPG_CHECK_HIP(hipMemcpyAsync(d_tab_all + g * 2 * fm, gens->table->d_table + gens->off_B(), sizeof(aniels_rec),
+                                         hipMemcpyDeviceToDevice, s));
+            if ((rc = table_build_shifted(ctx, d_tab_all, fpts, fold_c, fold_W))) return rc;
             cnp = fm;
             cstride = g * 2 * fm + 1;
             cblk = grid256(fm);
@@ -2100,17 +2109,12 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             if ((rc = gens_msm(gens, segs, 3, d_rowLR_all, NR, (int)(2 * g), lr.data(), 0.5f, HostPhase::IPP_SUBMIT, HostPhase::IPP_WAIT)))
                 return rc;     // half of every row is zero
         } else {
-            msm_seg segs[2] = {msm_seg{d_tab_all, g * 2 * fm, 0}, pedersen_seg(gens, 0, 1, g * 2 * fm)};
             bpg_msm_job *job = nullptr;
             {
                 HostPhase hp_s(HostPhase::IPP_SUBMIT);
-                if (fold_fb) {
-                    msm_seg one{d_tab_all, fpts, 0};              // B sits behind the tables, where the rows keep its scalar
-                    rc = msm_submit(ctx, &one, 1, d_rowLR_all, cstride, (int)(2 * g), false, &job,
-                                    msm_fixed_base{fold_c, fpts, 1.f / (float)(2 * g)}, 0);
-                } else {
-                    rc = msm_submit(ctx, segs, 2, d_rowLR_all, cstride, (int)(2 * g), false, &job, msm_fixed_base{0, 0, 1.f / (float)(2 * g)}, 0);
-                }
+                msm_seg one{d_tab_all, fpts, 0};                  // B sits behind the tables, where the rows keep its scalar
+                rc = msm_submit(ctx, &one, 1, d_rowLR_all, cstride, (int)(2 * g), false, &job,
+                                msm_fixed_base{fold_c, fpts, 1.f / (float)(2 * g)}, 0);
             }
             if (rc) return rc;
             HostPhase hp_w(HostPhase::IPP_WAIT);
@@ -2357,7 +2361,7 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     msm_seg gh[2] = {gen_seg(gens, 0, 0, ng, 0), gen_seg(gens, 1, 0, nh, ng)};
     msm_seg rest[2] = {{gens->table->d_table + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
     bpg_msm_job *job_f = nullptr, *job_d = nullptr;
-    if ((rc = msm_submit(ctx, gh, 2, d_gh, gh[0].len + gh[1].len, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->npoints()},
+    if ((rc = msm_submit(ctx, gh, 2, d_gh, gh[0].len + gh[1].len, 1, false, &job_f, msm_fixed_base{gens->fb_c, gens->fb_stride()},
                          ng + nh)))
         return rc;
     // From here on job_f's kernels read the lane's arena (d_gh): whatever happens to the second job, the first is

@@ -273,6 +273,17 @@ impl<'a, 'b> Prover<'a, 'b> {
         (CompressedRistretto(V), Variable::unpack(var))
     }
 
+    /// Not in upstream's API (optional; for one large proof).  Upstream's `prove` asks `thread_rng()` for 32 bytes and
+    /// then draws 2n + 3 blinding scalars from the transcript RNG, one Keccak permutation each, on the calling thread.
+    /// This call asks `thread_rng()` for those 32 bytes NOW -- after the last `commit`, before the gadget calls -- and
+    /// the library draws on a helper thread while the caller builds the circuit (`bpg_prover_begin_blindings`);
+    /// `prove` then uses those bytes.  The proof has the same distribution; a later `commit` simply stops the helper.
+    pub fn begin_blindings(&mut self) -> Result<(), R1CSError> {
+        let mut ext = [0u8; 32];
+        rand::thread_rng().fill_bytes(&mut ext);
+        check(unsafe { sys::bpg_prover_begin_blindings(self.raw, ext.as_ptr()) })
+    }
+
     /// `prove(bp_gens)`: external randomness from `rand::thread_rng()`, as in bulletproofs.
     pub fn prove(self, bp_gens: &BulletproofGens) -> Result<R1CSProof, R1CSError> {
         let mut rng = rand::thread_rng();
