@@ -587,8 +587,9 @@ def main():
                                   "frac": ach / (VMAD_PEAK_GMACS * world), "algorithmic_mac_per_proof": macs, "msm_points_per_proof": ppts,
                                   "reference_schedule_mac_per_proof": 2.88e10,
                                   "note": "whole prove() calls per second (host work included) x the bucket-accumulation MACs of the "
-                                          "schedule this library runs (fold-free first rounds, one fold, c = 13: 20 windows x 504 MAC per "
-                                          "point); the reference's own schedule would need 2.9e10 MAC per proof"}
+                                          "schedule this library runs (fold-free first rounds, one fold), every point priced at SURVEY 8d's canonical "
+                                          "window for these sizes (c = 13: 20 windows x 504 MAC; the library's own tables use 14-bit windows "
+                                          "and a 7-bit fold, so it executes fewer); the reference's own schedule would need 2.9e10 MAC per proof"}
             if world == 1 and not args.no_cpu_baseline:
                 cpu_s, cpu_proof = proof_cpu_baseline()
                 cores = host_cores()

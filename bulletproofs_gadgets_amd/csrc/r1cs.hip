@@ -1395,15 +1395,12 @@ int Prover::two_phase_prologue(R1CSProof &P) {
 }
 
 // Inner-product round after which finish_group materializes the folded generators (0: never; BPG_IPP_FOLD
-// overrides): when 2 x 4096 folded generators are left (2 x 2048 where the table has no half windows, or the group's
-// folded tables would pass 2^17 points).  With half windows the fold costs about 2.2 rounds' worth of additions
-// (3.4 without) whenever it is done; measured at 2^16 multipliers, 64 threads x 8 statements: 421 proofs/s with the
-// three-piece fold after round 5, 452 with the half-window fold after round 5, 462 after round 4.
-static int ipp_fold_default(size_t lg, size_t g, bool half_windows) {
-    if (lg < 12) return 0;
-    const bool wide = half_windows && lg >= 13 && g * 2 * 4096 + 1 <= ((size_t)1 << 17);
-    return (int)lg - (wide ? 12 : 11);
-}
+// overrides): when 2 x 2048 folded generators are left.  With the table's half windows the fold costs about 2.2
+// rounds' worth of additions (3.4 with three-piece digits) whenever it is done.  Measured at 2^16 multipliers, 64
+// threads x 8 statements: 421 proofs/s with the three-piece fold after round 5; with the half-window fold 452-455
+// after round 5 and 443-462 after round 4 (one fold-free round less, but twice the folded table, bucket sets and
+// later rounds: a wash, and the smaller tables win on memory).
+static int ipp_fold_default(size_t lg) { return lg >= 12 ? (int)lg - 11 : 0; }
 
 int Prover::prove(rng_fill_fn rng_fn, void *rng_user, R1CSProof &P) {
     int rc = prove_begin(rng_fn, rng_user);
@@ -1779,7 +1776,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     const size_t N1 = 2 * n + 1, NR = 2 * np + 1;
     const size_t nblk_n = grid_strip(n ? n : 1), nblk_np = grid256(np);
     // materialize the folded generators after round k0 (see msm_fold_submit): later rounds run on 2m points per proof
-    int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg, g, gens->tab_c != gens->fb_c) : ctx->tune.ipp_fold;
+    int k0 = ctx->tune.ipp_fold < 0 ? ipp_fold_default(lg) : ctx->tune.ipp_fold;
     if (gens->world != 1 || k0 < 1 || (size_t)k0 >= lg || (np >> k0) < 32) k0 = 0;
     // the rounds after the fold need the folded generators' own fixed-base table (below): no fold where that table
     // would pass 2^17 points or a side keeps more than 4096 generators (sizes this path has not been run at)

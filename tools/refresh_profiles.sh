@@ -17,3 +17,9 @@ echo fetch done >> $O/progress.log
 echo write done >> $O/progress.log
 (cd $R && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prove_stats -- python3 tools/prove_many_timing.py 8 1 > $O/prove_stats.log 2>&1)
 echo prove done >> $O/progress.log
+(cd $R && timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/prove_pmc -- python3 tools/prove_many_timing.py 8 1 > $O/prove_pmc.log 2>&1)
+echo prove pmc done >> $O/progress.log
+(cd $R && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prove_stats_t24 -- python3 tools/prove_many_timing.py 8 24 > $O/prove_stats_t24.log 2>&1)
+cd $R && python3 tools/kconcurrency.py gpurun_out/final/prove_stats_t24 > $O/prove_concurrency_t24.txt
+rm -f $O/prove_stats_t24/*/*kernel_trace.csv $O/msm_stats/*/*kernel_trace.csv $O/prove_stats/*/*kernel_trace.csv
+echo all done >> $O/progress.log
