@@ -92,7 +92,8 @@ int bpg_msm_submit(bpg_ctx *ctx, const bpg_points *pts, const void *d_scalars, s
 int bpg_msm_wait(bpg_msm_job *job, uint8_t *out32);
 
 /* The entry point that allocates nothing.  No counterpart in the reference: it is for callers that cannot call
- * hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same result as
+ * hipMalloc -- tight serving loops, harnesses that forbid allocation, code under HIP graph capture (only kernel launches and
+ * hipMemsetAsync on the caller's stream; not tested under capture here).  Same result as
  * bpg_msm_submit + bpg_msm_wait with one target: d_out32[0..32) = compress( sum_i d_scalars[i] * pts[i] ), i < n.
  * d_scalars and d_out32 are DEVICE pointers, `stream` a hipStream_t (NULL: the null stream); every kernel is enqueued
  * on that stream and the call returns without synchronising: the result is there when the stream reaches that point.
