@@ -271,6 +271,8 @@ def proof_cpu_baseline_all_cores(cores, nbits=PROOF_BITS):
 
 
 def main():
+    if os.environ.get("BPG_BENCH_SWITCHINTERVAL"):      # experiment: interpreter lock hand-over between the prover threads
+        sys.setswitchinterval(float(os.environ["BPG_BENCH_SWITCHINTERVAL"]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

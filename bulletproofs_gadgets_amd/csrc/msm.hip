@@ -783,17 +783,51 @@ k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ 
              level_ref lv0, const uint32_t *__restrict__ map0, ge_rec *__restrict__ parts, uint32_t nblk, int ls0, seg_map map,
              uint32_t wstride, uint32_t blk0) {
     uint32_t t = (blk0 + blockIdx.x) * 256u + threadIdx.x;
-    if (t >= lv0.base[nblk]) return;
-    const uint32_t g = map0[t];
-    const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
-    uint32_t cnt = counts[g];
-    uint32_t off = ent_off[g];
-    // the bucket's k = ceil(cnt / S0) threads share its entries evenly (sizes differ by at most one): with fixed
-    // S0-entry segments the last one is half empty on average and its lane idles while the wave runs S0 steps
-    const uint32_t k = (cnt + (uint32_t)ls0 - 1) / (uint32_t)ls0;
-    const uint32_t base = cnt / k, rem = cnt - base * k;
-    const uint32_t lo = rank * base + (rank < rem ? rank : rem);
-    const uint32_t hi = lo + base + (rank < rem ? 1u : 0u);
+    uint32_t e = 0, eend = 0;
+    if (t < lv0.base[nblk]) {
+        const uint32_t g = map0[t];
+        const uint32_t rank = t - (lv0.local[g] + lv0.base[g >> 10]);
+        const uint32_t cnt = counts[g];
+        const uint32_t off = ent_off[g];
+        // the bucket's k = ceil(cnt / S0) threads share its entries evenly (sizes differ by at most one): with fixed
+        // S0-entry segments the last one is half empty on average and its lane idles while the wave runs S0 steps
+        const uint32_t k = (cnt + (uint32_t)ls0 - 1) / (uint32_t)ls0;
+        const uint32_t base = cnt / k, rem = cnt - base * k;
+        const uint32_t lo = rank * base + (rank < rem ? rank : rem);
+        e = off + lo;
+        eend = e + base + (rank < rem ? 1u : 0u);
+    }
+    // Segments still differ in length (14, 15 or 16 entries under uniform digits) and a wave runs as long as its longest
+    // lane: the block's 256 segments are dealt to its lanes in order of length (a counting sort in LDS), so that each of
+    // its four waves gets segments of one length, or two.  Which lane sums a segment does not change the sum.
+    if (ls0 < 64) {
+        __shared__ uint32_t s_bin[64], s_e[256], s_end[256], s_t[256];
+        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t len = eend - e;                     // 0 (no segment: past the end) .. S0
+        const uint32_t mine = atomicAdd(&s_bin[len], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t v = s_bin[threadIdx.x];
+            uint32_t x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(x, o, 64);
+                if ((int)threadIdx.x >= o) x += y;
+            }
+            s_bin[threadIdx.x] = x - v;
+        }
+        __syncthreads();
+        const uint32_t pos = 255u - (s_bin[len] + mine);   // longest first: the empty segments end up in the last wave
+        s_e[pos] = e;
+        s_end[pos] = eend;
+        s_t[pos] = t;
+        __syncthreads();
+        e = s_e[threadIdx.x];
+        eend = s_end[threadIdx.x];
+        t = s_t[threadIdx.x];
+    }
+    if (e >= eend) return;
     // variable-base: wstride = 0 and the entry is index | sign; fixed-base: window w's copy of point i
     // (2^(c w) P_i) lives wstride records further per window (<= 64 windows)
     auto record = [&](uint32_t en) {
@@ -802,13 +836,6 @@ k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ 
         return record_of<MULTI>(map, idx) + (size_t)win * wstride;
     };
     ge acc;
-    uint32_t e = off + lo;
-    const uint32_t eend = off + hi;
-    if (e >= eend) {                                       // (cannot happen: a thread exists for >= 1 entry)
-        ge_identity(acc);
-        store_ge(parts + t, acc);
-        return;
-    }
     uint32_t en = entries[e];
     {
         ge_aniels_signed q;                                // identity + P = P
