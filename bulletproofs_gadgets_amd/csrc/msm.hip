@@ -800,21 +800,25 @@ k_accumulate(const uint32_t *__restrict__ entries, const uint32_t *__restrict__ 
     // Segments still differ in length (14, 15 or 16 entries under uniform digits) and a wave runs as long as its longest
     // lane: the block's 256 segments are dealt to its lanes in order of length (a counting sort in LDS), so that each of
     // its four waves gets segments of one length, or two.  Which lane sums a segment does not change the sum.
-    if (ls0 < 64) {
-        __shared__ uint32_t s_bin[64], s_e[256], s_end[256], s_t[256];
-        if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+    if (ls0 < 256) {
+        __shared__ uint32_t s_bin[256], s_wave[4], s_e[256], s_end[256], s_t[256];
+        s_bin[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t len = eend - e;                     // 0 (no segment: past the end) .. S0
         const uint32_t mine = atomicAdd(&s_bin[len], 1u);
         __syncthreads();
-        if (threadIdx.x < 64) {
+        {                                                  // exclusive scan of the 256 bins: lane scan, then the waves' totals
             const uint32_t v = s_bin[threadIdx.x];
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             uint32_t x = v;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t y = __shfl_up(x, o, 64);
-                if ((int)threadIdx.x >= o) x += y;
+                if (lane >= o) x += y;
             }
+            if (lane == 63) s_wave[wave] = x;
+            __syncthreads();
+            for (int w = 0; w < wave; w++) x += s_wave[w];
             s_bin[threadIdx.x] = x - v;
         }
         __syncthreads();
@@ -1184,11 +1188,14 @@ msm_plan make_plan(size_t n, int T, const msm_tuning &tune, int fixed_c, float d
     pl.W = windows_for(c);
     pl.Wb = fixed_c ? 1 : pl.W;
     pl.NB = 1 << (c - 1);
-    // S0 = entries per accumulate thread (any integer).  Measured: shrinking S0 so that a proof-sized MSM's threads
-    // just fill the machine does not pay -- the pass is bound by total additions once two waves share a SIMD, and
-    // more partials make the merge passes longer.
+    // S0 = entries per accumulate thread (any integer).  32 since the pass deals a block's segments to its lanes by
+    // length (k_accumulate): half the partial sums of S0 = 16, so half the merge pass, and the longer segments no
+    // longer cost the pass lanes that idle behind a wave's longest one.  2^20 points, four in flight: 1.03-1.05 ms per
+    // MSM at 16, 0.965-0.98 at 32-56; 2^16 ... 2^22: equal or better at every size but 2^18 (-3 %); proofs/s
+    // unchanged (profiles/r03_msm_segment_sweep.txt).  Before that sort, 16 ... 64 were all within 1 %.
+    // Shrinking S0 so that a proof-sized MSM's threads just fill the machine does not pay either.
     (void)resident_lanes;
-    pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 256) ? tune.ls0 : 16;
+    pl.ls0 = (tune.ls0 >= 1 && tune.ls0 <= 256) ? tune.ls0 : 32;
     pl.ls1 = (tune.ls1 >= 1 && tune.ls1 <= 8) ? tune.ls1 : 4;
     pl.P = pl.ls0;
     // passes: S0 * S1^R >= the most entries one bucket can hold
@@ -1727,7 +1734,7 @@ int msm_fold_submit(bpg_ctx *ctx, const msm_seg segs[2], const void *d_scalars, 
     bpg_msm_job *j = acquire_job(lane);
     if (!j) return BPG_EDEVICE;
     const int c = fb.c, W = windows_for(c);
-    const int S0 = 16, LS1 = 4;
+    const int S0 = 32, LS1 = 4;            // a 7-bit bucket holds 18 entries on average: one segment, nothing to merge
     const size_t ntargets = (size_t)rows * 2 * m, sets = ntargets * fs.P;
     const size_t NE = sets << fs.PB;                       // buckets
     const size_t M = (size_t)rows * fs.P * W * n;          // upper bound on entries
