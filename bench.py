@@ -40,7 +40,9 @@ sys.path.insert(0, ROOT)
 VMAD_PEAK_GMACS = 39321.6
 VMAD_MEASURED_GMACS = 37062.1
 # HBM-side bytes of one k_accumulate launch at 2^20 points, from rocprofv3 PMC passes (FETCH_SIZE doubled per the
-# guide's gfx950 correction, WRITE_SIZE as read): profiles/r02_pmc_*.csv.  bench.py cannot collect PMC itself.
+# guide's gfx950 correction, WRITE_SIZE as read): profiles/r02_pmc_*.csv, re-measured in round 3 with the same result
+# (profiles/r03_pmc_fetch_size.csv: 1.424 GB-units per launch; r03_pmc_write_size.csv: 0.156 GB).  bench.py cannot collect PMC
+# itself (a counter run serialises the kernels): the figure is a constant here, refreshed by tools/refresh_profiles.sh.
 ACC_TRAFFIC_BYTES_2_20 = 3.00e9          # 2 x 1.42 GB fetched + 0.16 GB written (gathered table lines: every point is read once per window)
 # field mul = 72 MAC, mixed add = 7M = 504 MAC, canonical c = 16 -> 16 windows.
 MAC_PER_POINT_ACCUMULATE = 16 * 504          # bucket accumulation only (the dominant kernel)
