@@ -39,5 +39,7 @@ echo "built tests/native/libhost_hooks.so"
 if [[ "${BPG_BUILD_TOOLS:-0}" == "1" ]]; then
     $HIPCC -O3 --offload-arch=${ARCH} tools/irate.hip -o tools/irate
     $HIPCC -O3 --offload-arch=${ARCH} tools/ubench.hip -o tools/ubench
-    echo "built tools/irate tools/ubench"
+    g++ -O2 -std=c++17 -Iinclude tools/native/prove_driver.cpp -o tools/native/prove_driver -Lbulletproofs_gadgets_amd -lbpg \
+        -Wl,-rpath,'$ORIGIN/../../bulletproofs_gadgets_amd' -Wl,-rpath,/opt/rocm/lib -lpthread
+    echo "built tools/irate tools/ubench tools/native/prove_driver"
 fi
