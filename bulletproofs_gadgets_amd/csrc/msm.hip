@@ -1587,7 +1587,11 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
         BPG_CHECK_HIP(hipMemcpyAsync(j->d_stage, d_scalars, (size_t)T * n * 32, hipMemcpyHostToDevice, s));
         d_sc = (const uint32_t *)j->d_stage;
     }
-    const msm_bufs b{j->d_digits, j->d_entries, j->d_counts, j->d_tmp, j->d_partials, j->d_chunk, j->d_out};
+    // the tail's few KB of output go straight to the job's pinned host buffer (device-visible at the same address): one
+    // command less per MSM on the stream, and no hop through a copy engine between the last kernel and the host's wait
+    static const bool zero_copy = getenv("BPG_NO_ZEROCOPY_OUT") == nullptr;
+    const bool direct_out = zero_copy && g.b_out <= ((size_t)1 << 18);
+    const msm_bufs b{j->d_digits, j->d_entries, j->d_counts, j->d_tmp, j->d_partials, j->d_chunk, direct_out ? j->h_out : j->d_out};
     const msm_layout y = msm_lay_out(g, b);
     msm_enqueue_sort(s, pl, g, b, y, d_sc, n, T, mm.smap, fb.c ? 1 : 0);
     // Accumulate passes of one lane's jobs run one after another: two of them at once only time-slice the
@@ -1597,7 +1601,7 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *d_scalar
     lane->acc_gate_job = j;
     msm_enqueue_merge_tail(s, pl, g, b, y, T);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, g.b_out, hipMemcpyDeviceToHost, s));
+    if (!direct_out) BPG_CHECK_HIP(hipMemcpyAsync(j->h_out, j->d_out, g.b_out, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(hipEventRecord(j->ev[3], s));
     release.j = nullptr;
     *out_job = j;

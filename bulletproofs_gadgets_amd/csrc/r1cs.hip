@@ -742,9 +742,38 @@ struct Arena {
 static size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // Pinned staging for the small transfers of one prove / verify call (lane->h_io): a bump allocator that the call sizes up
-// front.  h2d copies the source in and enqueues a plain DMA; d2h enqueues the DMA into the staging and remembers where the
-// bytes belong, collect() -- after the caller's next wait on the stream -- delivers them.  Where the staging cannot be had
-// (allocation failure, a call that outgrows its estimate) the transfer falls back to the pageable pointer.
+// front.  h2d copies the source into the staging, d2h reserves staging for the result; neither enqueues anything: the
+// pending items are moved by ONE kernel per flush() (k_small_copies: the device reads and writes the pinned host memory
+// directly).  A copy command per item -- six per proof and phase -- went through a copy engine and back to the compute
+// queue each time, and the copy engines' queues are FIFOs shared by every prover thread of the process, where a 32-byte
+// table waits behind another thread's 8 MB of witness: with the results of the MSMs written to pinned memory by their
+// last kernel (msm.hip) and these batched, proofs/s at 2^16 multipliers went from 446-449 to 481-494 and beyond.
+// flush() before the kernel that reads an uploaded item; flush() + wait + collect() delivers the downloads.  Where the
+// staging cannot be had (allocation failure, a call that outgrows its estimate) and for items above 64 KB the
+// transfer is a plain hipMemcpyAsync on the pageable / pinned pointer.
+struct small_copy {
+    void *dst;
+    const void *src;
+    uint32_t bytes, pad;
+};
+__global__ void __launch_bounds__(256) k_small_copies(const small_copy *__restrict__ items) {
+    const small_copy c = items[blockIdx.x];
+    if ((((uintptr_t)c.dst | (uintptr_t)c.src | (uintptr_t)c.bytes) & 15u) == 0) {
+        const uint4 *src = (const uint4 *)c.src;
+        uint4 *dst = (uint4 *)c.dst;
+        for (uint32_t i = threadIdx.x; i < c.bytes / 16; i += 256) dst[i] = src[i];
+    } else {
+        const uint32_t *src = (const uint32_t *)c.src;
+        uint32_t *dst = (uint32_t *)c.dst;
+        for (uint32_t i = threadIdx.x; i < c.bytes / 4; i += 256) dst[i] = src[i];
+    }
+}
+
+// one contiguous move of 16-byte units by the device itself (pinned host memory on one side)
+__global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 struct PinArena {
     bpg_lane *lane;
     size_t used = 0;
@@ -753,7 +782,9 @@ struct PinArena {
         const void *src;
         size_t bytes;
     };
-    std::vector<Pending> pending;
+    std::vector<Pending> pending;          // downloads: staging -> where the host wants them (collect)
+    std::vector<small_copy> batch;         // device-side moves of the next flush
+    static constexpr size_t SMALL = (size_t)1 << 16;
     explicit PinArena(bpg_lane *l) : lane(l) {}
     void reserve(size_t bytes) { (void)grow_pinned(&lane->h_io, &lane->h_io_cap, bytes); }
     void *take(size_t bytes) {
@@ -764,20 +795,42 @@ struct PinArena {
         return p;
     }
     hipError_t h2d(void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
-        if (void *st = take(bytes)) {
-            memcpy(st, h_src, bytes);
-            h_src = st;
+        void *st = take(bytes);
+        if (st) memcpy(st, h_src, bytes);
+        if (st && bytes <= SMALL && bytes % 4 == 0) {
+            batch.push_back({d_dst, st, (uint32_t)bytes, 0});
+            return hipSuccess;
         }
-        return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s);
+        return hipMemcpyAsync(d_dst, st ? st : h_src, bytes, hipMemcpyHostToDevice, s);
     }
     hipError_t d2h(void *h_dst, const void *d_src, size_t bytes, hipStream_t s) {
-        if (void *st = take(bytes)) {
-            pending.push_back({h_dst, st, bytes});
-            h_dst = st;
+        void *st = take(bytes);
+        if (st) pending.push_back({h_dst, st, bytes});
+        if (st && bytes <= SMALL && bytes % 4 == 0) {
+            batch.push_back({st, d_src, (uint32_t)bytes, 0});
+            return hipSuccess;
         }
-        return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s);
+        return hipMemcpyAsync(st ? st : h_dst, d_src, bytes, hipMemcpyDeviceToHost, s);
     }
-    void collect() {                       // after a wait on the stream
+    // enqueue the batched moves (before the kernel that reads an upload; before the wait that precedes collect)
+    hipError_t flush(hipStream_t s) {
+        if (batch.empty()) return hipSuccess;
+        const size_t n = batch.size();
+        small_copy *items = (small_copy *)take(n * sizeof(small_copy));
+        if (!items) {                         // no room for the list: item by item after all
+            for (const small_copy &c : batch) {
+                hipError_t e = hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDefault, s);
+                if (e != hipSuccess) return e;
+            }
+            batch.clear();
+            return hipSuccess;
+        }
+        memcpy(items, batch.data(), n * sizeof(small_copy));
+        batch.clear();
+        hipLaunchKernelGGL(k_small_copies, dim3((unsigned)n), dim3(256), 0, s, (const small_copy *)items);
+        return hipGetLastError();
+    }
+    void collect() {                       // after flush() and a wait on the stream
         for (auto &p : pending) memcpy(p.dst, p.src, p.bytes);
         pending.clear();
     }
@@ -1014,6 +1067,7 @@ static int gpu_flatten(bpg_lane *lane, Arena &ar, PinArena &pin, const Constrain
     sc *d_ztbl = ar.take<sc>(32), *d_zpow = ar.take<sc>(Q ? Q : 1), *d_coeffs = ar.take<sc>(cs.coeffs.size() ? cs.coeffs.size() : 1);
     BPG_CHECK_HIP(pin.h2d(d_ztbl, ztbl, sizeof ztbl, s));
     if (!cs.coeffs.empty()) BPG_CHECK_HIP(pin.h2d(d_coeffs, cs.coeffs.data(), cs.coeffs.size() * sizeof(sc), s));
+    BPG_CHECK_HIP(pin.flush(s));
     if (Q) hipExtLaunchKernelGGL(k_zpow, dim3(grid_strip(Q)), dim3(256), 0, s, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0, d_ztbl, d_zpow, Q);
     if (fp.nslots)
         hipExtLaunchKernelGGL(k_flatten, dim3(grid256(fp.nslots)), dim3(256), 0, s, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, 0, fc.d_off,
@@ -1130,17 +1184,25 @@ static int pedersen_batch(Gens *g, const sc *vr, size_t m, uint8_t *out32) {
     if ((rc = grow(&lane->d_io, &lane->io_cap, m * 96))) return rc;
     sc *d_s = (sc *)lane->d_io;
     uint8_t *d_o = (uint8_t *)lane->d_io + m * 64;
-    // both directions through pinned staging of the lane's own (plain DMAs: no wait inside the runtime)
+    // Both directions through pinned staging of the lane's own, moved by the device: a copy kernel brings the scalars in
+    // (16 lanes read each pair: not over the bus), and k_pedersen writes the 32-byte results straight to the host
+    // buffer.  No copy-engine command on the stream (see PinArena).  Without the staging: plain copies.
     uint8_t *h_in = nullptr, *h_out = nullptr;
     if (grow_pinned(&lane->h_ped, &lane->h_ped_cap, m * 96) == BPG_OK) {
         h_in = (uint8_t *)lane->h_ped;
         h_out = h_in + m * 64;
         memcpy(h_in, vr, m * 64);
     }
-    BPG_CHECK_HIP(hipMemcpyAsync(d_s, h_in ? (const void *)h_in : (const void *)vr, m * 64, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m, d_o);
+    if (h_in) {
+        const unsigned nb = (unsigned)((m * 4 + 255) / 256);
+        hipLaunchKernelGGL(k_copy16, dim3(nb < 64 ? nb : 64), dim3(256), 0, s, (uint4 *)d_s, (const uint4 *)h_in, (uint32_t)(m * 4));
+    } else {
+        BPG_CHECK_HIP(hipMemcpyAsync(d_s, vr, m * 64, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_pedersen, dim3((unsigned)((m * 16 + 255) / 256)), dim3(256), 0, s, (const aniels_rec *)g->d_comb, d_s, (uint32_t)m,
+                       h_out ? h_out : d_o);
     BPG_CHECK_HIP(hipGetLastError());
-    BPG_CHECK_HIP(hipMemcpyAsync(h_out ? h_out : out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
+    if (!h_out) BPG_CHECK_HIP(hipMemcpyAsync(out32, d_o, m * 32, hipMemcpyDeviceToHost, s));
     BPG_CHECK_HIP(lane_sync(lane));
     if (h_out) memcpy(out32, h_out, m * 32);
     return BPG_OK;
@@ -1873,6 +1935,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             }
         }
     }
+    BPG_CHECK_HIP(pin.flush(s));
     BPG_CHECK_HIP(lane_sync(lane));
     keep_sL.clear();
     keep_sR.clear();
@@ -1968,6 +2031,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         f.wV.resize(m);
         pgrp.p[j] = poly_proof{f.d_aL, f.d_aR, f.d_aO, f.d_sL, f.d_sR, f.d_W, f.d_ytbl, f.d_yinvtbl, f.d_l1, f.d_r0, f.d_r1, f.d_r3, f.d_part};
     }
+    BPG_CHECK_HIP(pin.flush(s));
     if (n) {
         hipExtLaunchKernelGGL(k_poly, dim3((unsigned)nblk_n, (unsigned)g), dim3(256), 0, s, evk ? evk[4] : nullptr, evk ? evk[5] : nullptr, 0,
                               (uint32_t)n, pgrp);
@@ -1979,6 +2043,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         if (n) BPG_CHECK_HIP(pin.d2h(f.h_part.data(), f.d_part, nblk_n * 6 * 32, s));
         if (m) BPG_CHECK_HIP(pin.d2h(f.wV.data(), f.d_W + 3 * n, m * 32, s));
     }
+    BPG_CHECK_HIP(pin.flush(s));
     BPG_CHECK_HIP(lane_sync(lane));
     pin.collect();
 
@@ -2139,6 +2204,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         BPG_CHECK_HIP(pin.d2h(&hab[2 * j], pf[j].d_a, 32, s));
         BPG_CHECK_HIP(pin.d2h(&hab[2 * j + 1], pf[j].d_b, 32, s));
     }
+    BPG_CHECK_HIP(pin.flush(s));
     BPG_CHECK_HIP(lane_sync(lane));
     pin.collect();
     const double ipp_ms = (now_ms() - t3) / (double)g, t_end = now_ms();
@@ -2307,6 +2373,7 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     BPG_CHECK_HIP(pin.h2d(d_yinvtbl, yinvtbl, sizeof yinvtbl, s));
     BPG_CHECK_HIP(pin.h2d(d_uk, uk.data(), (lg + 1) * 32, s));
     BPG_CHECK_HIP(pin.h2d(d_ukinv, ukinv.data(), (lg + 1) * 32, s));
+    BPG_CHECK_HIP(pin.flush(s));
     verify_args A{x.v, P.a.v, P.b.v, u.v, (uint32_t)n, (uint32_t)np, (uint32_t)lg, (uint32_t)n1};
     // scalar row order = table order: [ g (G) | h (H) | B | B~ | dyn ]
     hipLaunchKernelGGL(k_verify_scalars, dim3((unsigned)nblk), dim3(256), 0, s, A, d_W, d_yinvtbl, d_uk, d_ukinv, d_sc, d_sc + np,
@@ -2316,6 +2383,7 @@ int Verifier::prepare(const R1CSProof &P, Gens *gens, rng_fill_fn rng_fn, void *
     BPG_CHECK_HIP(pin.d2h(h_part.data(), d_part, nblk * 32, s));
     if (m) BPG_CHECK_HIP(pin.d2h(wV.data(), d_W + 3 * n, m * 32, s));
     if (n_one) BPG_CHECK_HIP(pin.d2h(h_one.data(), d_one, n_one * 32, s));
+    BPG_CHECK_HIP(pin.flush(s));
     BPG_CHECK_HIP(lane_sync(lane));
     pin.collect();
     Scalar delta(0), wc(0);
