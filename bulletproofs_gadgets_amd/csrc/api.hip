@@ -34,6 +34,12 @@ __device__ __forceinline__ void store_aniels(aniels_rec *rec, const ge_aniels &q
     p[7] = make_uint4(nt.v[4], nt.v[5], nt.v[6], nt.v[7]);
 }
 
+// one contiguous move of 16-byte units by the device itself (pinned host memory on one side): a kernel on the stream
+// instead of a copy-engine command (r1cs.hip: PinArena)
+__global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 // CompressedRistretto::decompress per thread; invalid encodings raise *bad and store the identity
 __global__ void __launch_bounds__(256) k_decode(const uint8_t *__restrict__ in32, aniels_rec *__restrict__ table, size_t n,
                                                 uint32_t *__restrict__ bad) {
@@ -270,6 +276,21 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
     if ((rc = grow(&lane->d_io, &lane->io_cap, n * 32 + 256))) return rc;
     uint8_t *d_in = (uint8_t *)lane->d_io;
     uint32_t *d_flag = (uint32_t *)(d_in + n * 32);
+    // a proof's few dozen points (the verifier's commitments, T's, L's and R's): staged in pinned memory of the lane's
+    // own, read there by k_decode, and the count of bad encodings comes back through a 16-byte kernel copy -- no
+    // copy-engine command, no pageable transfer (the runtime waits inside those, spinning)
+    if (n <= 8192 && grow_pinned(&lane->h_dec, &lane->h_dec_cap, n * 32 + 64) == BPG_OK) {
+        uint8_t *h_in = (uint8_t *)lane->h_dec;
+        uint32_t *h_flag = (uint32_t *)(h_in + n * 32 + ((64 - (n * 32) % 64) % 64));
+        memcpy(h_in, host32, n * 32);
+        BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 16, lane->stream));
+        hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, (const uint8_t *)h_in, dst, n, d_flag);
+        hipLaunchKernelGGL(k_copy16, dim3(1), dim3(256), 0, lane->stream, (uint4 *)h_flag, (const uint4 *)d_flag, 1u);
+        BPG_CHECK_HIP(hipGetLastError());
+        BPG_CHECK_HIP(lane_sync(lane));
+        *n_bad = h_flag[0];
+        return BPG_OK;
+    }
     BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, lane->stream));
     BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, lane->stream));
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n, d_flag);
@@ -443,6 +464,7 @@ void bpg_shutdown(bpg_ctx *ctx) {
         if (lane->h_wit) (void)hipHostFree(lane->h_wit);
         if (lane->h_io) (void)hipHostFree(lane->h_io);
         if (lane->h_ped) (void)hipHostFree(lane->h_ped);
+        if (lane->h_dec) (void)hipHostFree(lane->h_dec);
         if (lane->d_vacc) (void)hipFree(lane->d_vacc);
         if (lane->d_vtail) (void)hipFree(lane->d_vtail);
         if (lane->ev_sync) (void)hipEventDestroy(lane->ev_sync);

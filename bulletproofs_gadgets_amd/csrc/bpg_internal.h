@@ -152,6 +152,8 @@ struct bpg_lane {
     size_t h_io_cap = 0;
     void *h_ped = nullptr;            // Pedersen batches
     size_t h_ped_cap = 0;
+    void *h_dec = nullptr;            // compressed points on their way to k_decode
+    size_t h_dec_cap = 0;
     void *d_vacc = nullptr;
     size_t vacc_cap = 0;
     void *d_vtail = nullptr;
@@ -204,6 +206,8 @@ bpg_lane *lane_of(bpg_ctx *ctx);
 // wait for the lane's stream (sleeping or spinning, per ctx->sync_block)
 hipError_t lane_sync(bpg_lane *lane);
 hipError_t wait_event(const bpg_ctx *ctx, hipEvent_t ev);
+// (api.hip) dst[0..n16) = src[0..n16) in 16-byte units, by the device
+__global__ void k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16);
 
 // One run of consecutive table records that an MSM reads; up to 4 per MSM, possibly from
 // different tables (generator table + a lane's per-proof points).

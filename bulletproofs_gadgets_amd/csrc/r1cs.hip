@@ -769,11 +769,6 @@ __global__ void __launch_bounds__(256) k_small_copies(const small_copy *__restri
     }
 }
 
-// one contiguous move of 16-byte units by the device itself (pinned host memory on one side)
-__global__ void __launch_bounds__(256) k_copy16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint32_t n16) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
-}
-
 struct PinArena {
     bpg_lane *lane;
     size_t used = 0;
@@ -2420,7 +2415,12 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     uint32_t bad = 0;
     if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
     if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
-    BPG_CHECK_HIP(hipMemcpyAsync(d_tail, tail.data(), tail.size() * 32, hipMemcpyHostToDevice, s));
+    {
+        PinArena pin(lane);            // (prepare's transfers are complete: the staging starts over)
+        pin.reserve(tail.size() * 32 + 4096);
+        BPG_CHECK_HIP(pin.h2d(d_tail, tail.data(), tail.size() * 32, s));
+        BPG_CHECK_HIP(pin.flush(s));
+    }
     BPG_CHECK_HIP(lane_sync(lane));
     // d_gh = [g[0..ng) | h[0..nh)]: each rank takes the generators it holds; rank 0 adds the rest
     msm_seg gh[2] = {gen_seg(gens, 0, 0, ng, 0), gen_seg(gens, 1, 0, nh, ng)};
