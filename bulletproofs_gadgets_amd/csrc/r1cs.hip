@@ -1865,7 +1865,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     {
         size_t pneed = 1 << 16;
         for (size_t j = 0; j < g; j++)
-            pneed += 4096 + 3 * 1024 + (ps[j]->cs_.coeffs.size() + 1) * 32 + nblk_n * 6 * 32 + (ps[j]->v_.size() + 1) * 32 + 64 * 8;
+            pneed += 4096 + 3 * 1024 + (ps[j]->cs_.coeffs.size() + 1) * 32 + nblk_n * 6 * 32 + (ps[j]->v_.size() + 1) * 32 + 64 * 8 +
+                     (n * 32 <= PinArena::SMALL ? 5 * (n * 32 + 64) : 0);
         pin.reserve(pneed);
     }
     std::unique_ptr<HostPhase> hp_up(new HostPhase(HostPhase::UPLOAD));
@@ -1901,7 +1902,12 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
         BPG_CHECK_HIP(pin.h2d(f.d_rows + 2 * N1, &p.s_bl_, 32, s));
         if (n) {
             const sc *hL = p.a_L_.data(), *hR = p.a_R_.data(), *hO = p.a_O_.data();
-            if (h_wit) {
+            const bool small_wit = n * 32 <= PinArena::SMALL;       // a small circuit's vectors join the batched move
+            if (small_wit) {
+                BPG_CHECK_HIP(pin.h2d(f.d_aL, hL, n * 32, s));
+                BPG_CHECK_HIP(pin.h2d(f.d_aR, hR, n * 32, s));
+                BPG_CHECK_HIP(pin.h2d(f.d_aO, hO, n * 32, s));
+            } else if (h_wit) {
                 sc *w = (sc *)(h_wit + j * 3 * n * 32);
                 memcpy(w, hL, n * 32);
                 memcpy(w + n, hR, n * 32);
@@ -1910,9 +1916,11 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
                 hR = w + n;
                 hO = w + 2 * n;
             }
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, hL, (h_wit ? 2 : 1) * n * 32, hipMemcpyHostToDevice, s));   // staged: a_L | a_R are adjacent on both sides
-            if (!h_wit) BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
-            BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, hO, n * 32, hipMemcpyHostToDevice, s));
+            if (!small_wit) {
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, hL, (h_wit ? 2 : 1) * n * 32, hipMemcpyHostToDevice, s));   // staged: a_L | a_R are adjacent on both sides
+                if (!h_wit) BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, hO, n * 32, hipMemcpyHostToDevice, s));
+            }
             const uint8_t *raw = p.s_raw_pin_ ? p.s_raw_pin_ : keep_raw[j].empty() ? nullptr : keep_raw[j].data();
             if (p.spec_) {                           // early draws: streamed below, once A_I and A_O are under way
                 if (g != 1) return BPG_EINVAL;
@@ -1925,8 +1933,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
                 hipLaunchKernelGGL(k_reduce512, dim3(grid256(2 * n)), dim3(256), 0, s, d_raw, f.d_sL, (uint32_t)(2 * n));
             } else {
                 if (keep_sL[j].size() != n || keep_sR[j].size() != n) return BPG_EINVAL;
-                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sL, keep_sL[j].data(), n * 32, hipMemcpyHostToDevice, s));
-                BPG_CHECK_HIP(hipMemcpyAsync(f.d_sR, keep_sR[j].data(), n * 32, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(pin.h2d(f.d_sL, keep_sL[j].data(), n * 32, s));      // (batched when small; a plain copy otherwise)
+                BPG_CHECK_HIP(pin.h2d(f.d_sR, keep_sR[j].data(), n * 32, s));
             }
         }
     }
@@ -2132,8 +2140,8 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
                                       d_tab_all, &job)))
                 return rc;
             if ((rc = msm_fold_wait(job))) return rc;
-            BPG_CHECK_HIP(hipMemcpyAsync(d_tab_all + g * 2 * fm, gens->table->d_table + gens->off_B(), sizeof(aniels_rec),
-                                         hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(k_copy16, dim3(1), dim3(256), 0, s, (uint4 *)(d_tab_all + g * 2 * fm),
+                               (const uint4 *)(gens->table->d_table + gens->off_B()), (uint32_t)(sizeof(aniels_rec) / 16));
             if ((rc = table_build_shifted(ctx, d_tab_all, fpts, fold_c, fold_W))) return rc;
             cnp = fm;
             cstride = g * 2 * fm + 1;
