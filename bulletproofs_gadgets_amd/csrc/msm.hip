@@ -1259,6 +1259,9 @@ int grow_pinned(void **p, size_t *cap, size_t need) {
     *p = nullptr;
     *cap = 0;
     size_t want = need + need / 8 + 4096;
+    // no flags = COHERENT host memory in HIP's rules (HIP_HOST_COHERENT is ignored then): kernels that write results
+    // straight into these buffers (MSM tails, k_pedersen, k_small_copies) rely on it -- their stores are not cached on
+    // the device and are visible to the host once the stream's event has completed
     if (hipHostMalloc(p, want, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         *p = nullptr;
