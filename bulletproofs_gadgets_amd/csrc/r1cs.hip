@@ -1880,7 +1880,12 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
     uint4 *spec_d_raw = nullptr;
     double spec_wait_ms = 0;                               // of the commit phase: waiting for the helper's draws
     // the witness vectors go through the lane's pinned staging too (one host copy, then DMA)
-    uint8_t *h_wit = n && grow_pinned(&lane->h_wit, &lane->h_wit_cap, g * 3 * n * 32) == BPG_OK ? (uint8_t *)lane->h_wit : nullptr;
+    uint8_t *h_wit = n && grow_pinned(&lane->h_wit, &lane->h_wit_cap, g * (3 * n + 1) * 32) == BPG_OK ? (uint8_t *)lane->h_wit : nullptr;
+    // the group's raw draws in one piece (device side), when the host side is one piece too (prove_many's pinned chunk)
+    bool raw_whole = g > 1 && n && lane->h_raw != nullptr;
+    for (size_t j = 0; j < g && raw_whole; j++)
+        raw_whole = !ps[j]->spec_ && ps[j]->s_raw_pin_ == (uint8_t *)lane->h_raw + j * 128 * n;
+    uint4 *d_raw_whole = raw_whole ? (uint4 *)ar.take<uint8_t>(g * 128 * n) : nullptr;
     for (size_t j = 0; j < g; j++) {
         Prover &p = *ps[j];
         PF &f = pf[j];
@@ -1908,17 +1913,17 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
                 BPG_CHECK_HIP(pin.h2d(f.d_aR, hR, n * 32, s));
                 BPG_CHECK_HIP(pin.h2d(f.d_aO, hO, n * 32, s));
             } else if (h_wit) {
-                sc *w = (sc *)(h_wit + j * 3 * n * 32);
+                // rows 0 and 1 are adjacent on the device -- [i_bl | a_L | a_R] [o_bl | a_O | 0] -- so a_L | a_R | o_bl | a_O is
+                // ONE transfer (each command for the copy engines is a turn in their queues; see PinArena)
+                sc *w = (sc *)(h_wit + j * (3 * n + 1) * 32);
                 memcpy(w, hL, n * 32);
                 memcpy(w + n, hR, n * 32);
-                memcpy(w + 2 * n, hO, n * 32);
-                hL = w;
-                hR = w + n;
-                hO = w + 2 * n;
-            }
-            if (!small_wit) {
-                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, hL, (h_wit ? 2 : 1) * n * 32, hipMemcpyHostToDevice, s));   // staged: a_L | a_R are adjacent on both sides
-                if (!h_wit) BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
+                w[2 * n] = p.o_bl_;
+                memcpy(w + 2 * n + 1, hO, n * 32);
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, w, (3 * n + 1) * 32, hipMemcpyHostToDevice, s));
+            } else {
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aL, hL, n * 32, hipMemcpyHostToDevice, s));
+                BPG_CHECK_HIP(hipMemcpyAsync(f.d_aR, hR, n * 32, hipMemcpyHostToDevice, s));
                 BPG_CHECK_HIP(hipMemcpyAsync(f.d_aO, hO, n * 32, hipMemcpyHostToDevice, s));
             }
             const uint8_t *raw = p.s_raw_pin_ ? p.s_raw_pin_ : keep_raw[j].empty() ? nullptr : keep_raw[j].data();
@@ -1928,8 +1933,9 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             } else if (raw) {                        // raw draws: reduced mod l on the device, straight into row 2
                 if (!p.s_raw_pin_ && keep_raw[j].size() != 128 * n) return BPG_EINVAL;
                 p.s_raw_pin_ = nullptr;
-                uint4 *d_raw = (uint4 *)ar.take<uint8_t>(128 * n);
-                BPG_CHECK_HIP(hipMemcpyAsync(d_raw, raw, 128 * n, hipMemcpyHostToDevice, s));
+                uint4 *d_raw = d_raw_whole ? d_raw_whole + j * 8 * n : (uint4 *)ar.take<uint8_t>(128 * n);
+                if (!d_raw_whole) BPG_CHECK_HIP(hipMemcpyAsync(d_raw, raw, 128 * n, hipMemcpyHostToDevice, s));
+                else if (j == 0) BPG_CHECK_HIP(hipMemcpyAsync(d_raw_whole, lane->h_raw, g * 128 * n, hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_reduce512, dim3(grid256(2 * n)), dim3(256), 0, s, d_raw, f.d_sL, (uint32_t)(2 * n));
             } else {
                 if (keep_sL[j].size() != n || keep_sR[j].size() != n) return BPG_EINVAL;
