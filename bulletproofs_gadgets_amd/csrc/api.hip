@@ -268,7 +268,7 @@ int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, si
     return BPG_OK;
 }
 
-int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad) {
+int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad, const uint32_t **pending_bad) {
     *n_bad = 0;
     if (!n) return BPG_OK;
     BPG_LANE(ctx);
@@ -287,10 +287,15 @@ int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32,
         hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, (const uint8_t *)h_in, dst, n, d_flag);
         hipLaunchKernelGGL(k_copy16, dim3(1), dim3(256), 0, lane->stream, (uint4 *)h_flag, (const uint4 *)d_flag, 1u);
         BPG_CHECK_HIP(hipGetLastError());
+        if (pending_bad) {                     // the caller has more to enqueue before it waits: the count is *pending_bad then
+            *pending_bad = h_flag;
+            return BPG_OK;
+        }
         BPG_CHECK_HIP(lane_sync(lane));
         *n_bad = h_flag[0];
         return BPG_OK;
     }
+    if (pending_bad) *pending_bad = nullptr;   // (not taken: the count is in *n_bad on return)
     BPG_CHECK_HIP(hipMemcpyAsync(d_in, host32, n * 32, hipMemcpyHostToDevice, lane->stream));
     BPG_CHECK_HIP(hipMemsetAsync(d_flag, 0, 4, lane->stream));
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lane->stream, d_in, dst, n, d_flag);

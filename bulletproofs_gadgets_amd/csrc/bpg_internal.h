@@ -229,7 +229,10 @@ int msm_submit(bpg_ctx *ctx, const msm_seg *segs, int nseg, const void *scalars,
 // sc_stride != 0 (device scalars only): rows are sc_stride scalars apart and segment k reads
 // scalars[t*sc_stride + segs[k].sc_off ..): a rank of a sharded MSM reads its slices in place.
 int table_write_uniform(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host64, size_t n);
-int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad);
+// pending_bad != nullptr: where possible (few points) nothing is waited for -- *pending_bad then points at the count of
+// invalid encodings, valid after the caller's next wait on the lane's stream; nullptr in *pending_bad: *n_bad is set
+int table_write_compressed(bpg_ctx *ctx, aniels_rec *dst, const uint8_t *host32, size_t n, uint32_t *n_bad,
+                           const uint32_t **pending_bad = nullptr);
 // table holds W * npts records with records [0, npts) filled: fills [w * npts + i] = 2^(c w) P_i
 int table_build_shifted(bpg_ctx *ctx, aniels_rec *table, size_t npts, int c, int W);
 int msm_wait(bpg_msm_job *job, uint8_t *out, bool partial);

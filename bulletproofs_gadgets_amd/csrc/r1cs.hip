@@ -2427,7 +2427,8 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
     int rc;
     if ((rc = grow((void **)&lane->d_dyn, &lane->dyn_cap, (ndyn + 1) * sizeof(aniels_rec)))) return rc;
     uint32_t bad = 0;
-    if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad))) return rc;
+    const uint32_t *pending_bad = nullptr;      // decode and tail upload share one wait
+    if ((rc = table_write_compressed(ctx, lane->d_dyn, dyn.data(), ndyn, &bad, &pending_bad))) return rc;
     if (bad) return BPG_EVERIFY;       // a point failed to decompress (dalek: optional_multiscalar_mul -> None)
     {
         PinArena pin(lane);            // (prepare's transfers are complete: the staging starts over)
@@ -2436,6 +2437,7 @@ static int verify_msm(bpg_lane *lane, Gens *gens, const sc *d_gh, size_t ng, siz
         BPG_CHECK_HIP(pin.flush(s));
     }
     BPG_CHECK_HIP(lane_sync(lane));
+    if (pending_bad && *pending_bad) return BPG_EVERIFY;
     // d_gh = [g[0..ng) | h[0..nh)]: each rank takes the generators it holds; rank 0 adds the rest
     msm_seg gh[2] = {gen_seg(gens, 0, 0, ng, 0), gen_seg(gens, 1, 0, nh, ng)};
     msm_seg rest[2] = {{gens->table->d_table + gens->off_B(), 2}, {lane->d_dyn, ndyn}};
