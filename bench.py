@@ -157,10 +157,12 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
 
     ktimes = []
 
-    def one(tag, verify):
+    def one(tag, verify, early=False):
         bl, ext_p, ext_v = randomness(tag)
         p = g.Prover(gens, b"ScalarMul")
         comms, vars_ = p.commit_batch_raw(vals, bl)
+        if early:                                      # the blinding RNG's chain runs beside the capture (bpg_prover_begin_blindings)
+            p.begin_blindings(ext_p)
         E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
         proof = p.prove(gens, ext_p)
         kt = p.kernel_timing()
@@ -203,6 +205,10 @@ def proof_bench(ctx, rank, threads, per_thread, per_call, nbits=PROOF_BITS):
         t0 = time.perf_counter()
         one(b"lat%d" % verify, verify)
         lat.append((time.perf_counter() - t0) * 1e3)
+    assert one(b"parity", False, early=True).to_bytes() == first.to_bytes()
+    t0 = time.perf_counter()
+    one(b"lat-early", False, early=True)
+    lat.append((time.perf_counter() - t0) * 1e3)
     secs, cpu, cpu_sys = [], [], []
     for verify in (False, True, "batch"):
         errs = []
@@ -460,7 +466,9 @@ def main():
                   "prove_and_verify_batched": world * cnt / s_pvb,      # each call's proofs verified by one combined MSM
                   "multipliers": 27 * PROOF_BITS + 4, "proof_bytes": len(first_proof.to_bytes()),
                   "host_threads_per_gpu": args.proof_threads, "proofs_per_gpu": cnt, "proofs_per_call": args.proofs_per_call,
-                  "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1]},
+                  "single_proof_latency_ms": {"prove": lat[0], "prove_and_verify": lat[1], "prove_with_early_blinding_draws": lat[2],
+                                              "note": "capture + prove of one statement with the GPU to itself; the third figure hands the "
+                                                      "external randomness over after the commitments (bpg_prover_begin_blindings): same bytes"},
                   "host_cpu_ms_per_proof": {"prove": 1e3 * cpu_s3[0][0] / cnt, "prove_and_verify": 1e3 * cpu_s3[0][1] / cnt,
                                             "prove_kernel_mode": 1e3 * cpu_s3[1][0] / cnt,
                                             "note": "process CPU time (all host threads; waits poll with 20-100 us naps unless BPG_SYNC=spin / block) "
