@@ -1239,6 +1239,13 @@ hipError_t device_malloc(void **p, size_t bytes) {
         *p = nullptr;
         return hipErrorOutOfMemory;
     }
+    // fail at once when the device cannot hold the request (workspaces grow to GBs per prover thread: 64 threads in
+    // groups of sixteen ask for more than the 288 GB): asking the driver anyway was seen to stall for minutes
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
     return hipMalloc(p, bytes);
 }
 

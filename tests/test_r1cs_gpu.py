@@ -599,3 +599,18 @@ def test_early_blinding_draws_give_the_same_proof(gpu_ctx):
         del p                                      # a prover dropped with its helper running
     finally:
         gens.free()
+
+
+def test_oversized_generator_table_fails_at_once(gpu_ctx):
+    """a request the device cannot hold is refused without asking the driver (device_malloc checks the free memory):
+    capacity 2^26 would need 36 blocks x 2^27 records x 128 bytes = 618 GB"""
+    import time
+    import bulletproofs_gadgets_amd as bpg
+    from bulletproofs_gadgets_amd import r1cs as g
+    t0 = time.perf_counter()
+    with pytest.raises(bpg.BpgError) as e:
+        g.BulletproofGens(gpu_ctx, 1 << 26, 1)
+    assert "ENOMEM" in str(e.value)
+    assert time.perf_counter() - t0 < 5.0
+    gens = g.BulletproofGens(gpu_ctx, 64, 1)          # the context is as usable as before
+    gens.free()
