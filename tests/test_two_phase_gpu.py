@@ -216,3 +216,23 @@ def test_two_phase_prover_proves_once(gbe, rnd):
     with pytest.raises(bpg.BpgError) as e:
         r.prove(None, bytes(32))
     assert e.value.code == _native.EINVAL
+
+
+def test_early_blinding_draws_give_way_to_randomized_constraints(gbe, rnd):
+    """bpg_prover_begin_blindings on a prover that then registers randomized constraints: the helper is stopped (a
+    two-phase proof draws in two rounds) and the proof is the one prove() gives with that external randomness."""
+    xs = [rnd.randrange(1, R.L) for _ in range(4)]
+    ys = list(reversed(xs))
+    ext = bytes(range(32))
+    p0, _, bp, _ = _prove(gbe, xs, ys, b"eb")
+    want = p0.prove(bp, ext).to_bytes()
+
+    rng = R.SeededRng(b"eb")
+    p = gbe.Prover(gbe.Transcript(b"ShuffleProof"))
+    vars_ = []
+    for v in xs + ys:
+        _, var = p.commit(v, rng.scalar())
+        vars_.append(var)
+    p.begin_blindings(ext)                             # before the gadget registers its randomized constraints
+    rc.shuffle_gadget(p, vars_[:4], vars_[4:])
+    assert p.prove(bp, bytes(32)).to_bytes() == want      # prove's own randomness is not asked
