@@ -25,8 +25,10 @@ import time
 
 # More than two MSMs in flight need more hardware queues than HIP's default of 4: streams that share a queue
 # run in submission order, and a stream parked on the accumulate gate then holds up the others behind it.
+# 12: measured best for the MSM (0.97-0.99 ms against 1.00 at 8 and 1.01 at 16) and within 3 % of the best for proofs
+# (4 / 8 / 12 / 16 / 24 queues: 498 / 540 / 553 / 570 / 436 proofs/s with 64 prover threads).
 # (read by the HIP runtime when it starts, so set before anything loads it)
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("BPG_BENCH_HW_QUEUES", "8")
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("BPG_BENCH_HW_QUEUES", "12")
 # a proof that is proved alone (the latency leg) times its scalar-vector kernels with HIP events: secondary.scalar_kernels
 os.environ.setdefault("BPG_TIME_KERNELS", "1")
 
