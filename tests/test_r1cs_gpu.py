@@ -614,3 +614,32 @@ def test_oversized_generator_table_fails_at_once(gpu_ctx):
     assert time.perf_counter() - t0 < 5.0
     gens = g.BulletproofGens(gpu_ctx, 64, 1)          # the context is as usable as before
     gens.free()
+
+
+@pytest.mark.parametrize("nbits,k", [(40, 19), (150, 17)])
+def test_prove_many_in_chunks_of_sixteen(gpu_ctx, nbits, k):
+    """prove_many over more provers than one chunk holds (16), at sizes where the raw blinding draws go through the
+    lane's pinned staging (>= 256 multipliers) and, at 150 bits, where the generators are folded (half-window table):
+    chunks of 16, RNG lanes of 8 and a remainder must give the bytes of k separate prove() calls."""
+    import hashlib
+    from bulletproofs_gadgets_amd import r1cs as g
+    from tools import sharded_proof as sp
+    base, expected, vals, _, _, _ = sp.statement(nbits)
+    E = g.SonnyEdwardsPointGadget
+    n = 27 * nbits + 4
+    gens = g.BulletproofGens(gpu_ctx, 1 << (n - 1).bit_length(), 1)
+    try:
+        def build(j):
+            raw = hashlib.shake_256(b"chunks%d/%d" % (nbits, j)).digest(31 * nbits)
+            bl = b"".join(raw[31 * i:31 * i + 31] + b"\0" for i in range(nbits))
+            p = g.Prover(gens, b"ScalarMul")
+            _, vars_ = p.commit_batch_raw(vals, bl)
+            E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
+            return p
+        ext = b"".join(hashlib.sha256(b"ext%d" % j).digest() for j in range(k))
+        single = [build(j).prove(gens, ext[32 * j:32 * j + 32]).to_bytes() for j in range(k)]
+        many = g.Prover.prove_many([build(j) for j in range(k)], ext)
+        assert [p.to_bytes() for p in many] == single
+        assert len(set(single)) == k
+    finally:
+        gens.free()
