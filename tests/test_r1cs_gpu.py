@@ -643,3 +643,63 @@ def test_prove_many_in_chunks_of_sixteen(gpu_ctx, nbits, k):
         assert len(set(single)) == k
     finally:
         gens.free()
+
+
+def test_many_threads_groups_early_draws_and_batch_verification(gpu_ctx):
+    """Twelve host threads at once, each proving a group of four 4054-multiplier statements (folded generators, pinned
+    staging, batched small transfers), every third thread also proving one statement alone with early blinding draws
+    (the context's pool of draw buffers), each thread checking its proofs with one verify_batch: bytes equal the
+    serial run's, every batch accepted."""
+    import hashlib
+    import threading
+    from bulletproofs_gadgets_amd import r1cs as g
+    from tools import sharded_proof as sp
+    nbits, T, K = 150, 12, 4
+    base, expected, vals, _, _, _ = sp.statement(nbits)
+    E = g.SonnyEdwardsPointGadget
+    gens = g.BulletproofGens(gpu_ctx, 4096, 1)
+
+    def build(tag, early_ext=None):
+        raw = hashlib.shake_256(b"mt/" + tag).digest(31 * nbits)
+        bl = b"".join(raw[31 * i:31 * i + 31] + b"\0" for i in range(nbits))
+        p = g.Prover(gens, b"ScalarMul")
+        comms, vars_ = p.commit_batch_raw(vals, bl)
+        if early_ext is not None:
+            p.begin_blindings(early_ext)
+        E.scalar_mul(E.from_point(base), vars_, p).equal(E.from_point(expected), p)
+        return p, comms
+
+    def work(t):
+        ext = b"".join(hashlib.sha256(b"mt-ext%d/%d" % (t, j)).digest() for j in range(K))
+        built = [build(b"%d/%d" % (t, j)) for j in range(K)]
+        proofs = g.Prover.prove_many([p for p, _ in built], ext)
+        out = [q.to_bytes() for q in proofs]
+        if t % 3 == 0:
+            p, _ = build(b"%d/0" % t, early_ext=ext[:32])
+            assert p.prove(gens, bytes(32)).to_bytes() == out[0]
+        vs = []
+        for _, comms in built:
+            v = g.Verifier(b"ScalarMul")
+            E.scalar_mul(E.from_point(base), v.commit_batch_raw(comms.raw), v).equal(E.from_point(expected), v)
+            vs.append(v)
+        assert g.verify_batch(vs, proofs, gens, hashlib.shake_256(b"w%d" % t).digest(64 * K))
+        return out
+    try:
+        serial = [work(t) for t in range(3)]
+        res, errs = [None] * T, []
+
+        def run(t):
+            try:
+                res[t] = work(t)
+            except Exception as e:      # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                errs.append(repr(e))
+        th = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        assert res[:3] == serial
+        assert len({b for r in res for b in r}) == T * K
+    finally:
+        gens.free()
