@@ -1995,7 +1995,7 @@ int Prover::finish_group(Prover *const *ps, size_t g, R1CSProof *out) {
             memcpy(out[j].S1, &o[96 * j + 64], 32);
         }
     }
-    const double commit_ms = (now_ms() - t1) / (double)g;
+    const double commit_ms = (now_ms() - t1 - spec_wait_ms) / (double)g;      // (not the wait for a helper's draws: that is rng time)
 
     // ---- challenges y, z; flatten, l/r polynomials, t coefficients
     const double t2 = now_ms();
