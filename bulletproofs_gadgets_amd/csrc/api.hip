@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_shift_table(aniels_rec *__restrict__ ta
     fe prod;
     fe_set1(prod);
     for (int w = 1; w < W; w++) {
-        for (int k = 0; k < c; k++) ge_double(p, p);
+        for (int k = 0; k < c; k++) ge_double_xyz(p, p);      // T is never read: the chain only doubles, the records take X, Y, Z
         fe_mul(prod, prod, p.Z);
         ge tmp = p;
         tmp.T = prod;

@@ -149,6 +149,24 @@ BPG_HD void ge_double(ge &r, const ge &p) {
     fe_mul(r.T, cx, yypxx);
 }
 
+// the same without T (a doubling that is followed by another doubling, or by a conversion to affine)
+BPG_HD void ge_double_xyz(ge &r, const ge &p) {
+    fe xx, yy, zz2, xpy, s, yypxx, yymxx, cx, ct;
+    fe_sq(xx, p.X);
+    fe_sq(yy, p.Y);
+    fe_sq(zz2, p.Z);
+    fe_add(zz2, zz2, zz2);
+    fe_add(xpy, p.X, p.Y);
+    fe_sq(s, xpy);
+    fe_add(yypxx, yy, xx);
+    fe_sub(yymxx, yy, xx);
+    fe_sub(cx, s, yypxx);
+    fe_sub(ct, zz2, yymxx);
+    fe_mul(r.X, cx, ct);
+    fe_mul(r.Y, yypxx, yymxx);
+    fe_mul(r.Z, yymxx, ct);
+}
+
 BPG_FE_CONST(fe_half, 0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu)   // (p+1)/2
 
 // affine (x, y) -> halved affine Niels
